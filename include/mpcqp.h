@@ -1,0 +1,129 @@
+/*
+ * mpcqp.h -- C-ABI of the batched convex-MPC QP engine (libmpcqp.so, MI355X / gfx950).
+ *
+ * This is the drop-in boundary for ONE path of the reference
+ * (Emilianogith/MPC-for-dynamic-locomotion-in-the-MIT-cheetah-3): the QP that src/mpc.py builds once
+ * (MPC.__init__, src/mpc.py:25-173) and fills + solves every control tick (MPC.solve, src/mpc.py:176-303).
+ * The reference has no native boundary of its own: its solver call is CasADi's Opti('conic') -> "osqp"
+ * plugin (src/mpc.py:49-55, 258).  What crosses into that solver is the tuple of seven `opt.set_value`
+ * parameters (src/mpc.py:242-255) and what comes back is `sol.value(X)`, `sol.value(U)` (src/mpc.py:265-268).
+ * The entry points below are that tuple, batched and in compact form.
+ *
+ * The same symbols are exported by two libraries:
+ *   - libmpcqp.so         (product)  pointers are DEVICE memory on the handle's GPU, work is enqueued on `stream`;
+ *   - libmpcqp_oracle.so  (checker, oracle/) pointers are HOST memory, `stream` is ignored, fp64 only.
+ *
+ * All functions return 0 on success and a negative MPCQP_E* code on API misuse / HIP failure; the message is
+ * available from mpcqp_last_error().  Numerical outcomes are per-QP `status` values, never error returns
+ * (the reference would raise RuntimeError out of opt.solve(), src/mpc.py:258, with error_on_fail commented
+ * out at :53).
+ */
+#ifndef MPCQP_H_
+#define MPCQP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCQP_VERSION 0x00010000 /* 1.0.0 */
+
+/* return codes */
+#define MPCQP_OK 0
+#define MPCQP_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define MPCQP_EHIP (-2)     /* a HIP runtime call failed */
+#define MPCQP_ENOMEM (-3)   /* workspace allocation failed */
+#define MPCQP_ENODEV (-4)   /* no usable gfx950 device (the product library never falls back to the CPU) */
+
+/* per-QP status written to status[B] */
+#define MPCQP_STATUS_UNSOLVED 0
+#define MPCQP_STATUS_SOLVED_POLISHED 1 /* active-set polish passed its KKT check */
+#define MPCQP_STATUS_SOLVED_ADMM 2     /* ADMM residuals under eps_abs/eps_rel */
+#define MPCQP_STATUS_MAX_ITER 3        /* iteration cap reached; u is the last iterate */
+#define MPCQP_STATUS_NONFINITE (-1)    /* non-finite input or iterate; outputs zeroed */
+
+/* discretisation of the continuous single-rigid-body model (src/mpc.py:86-107) */
+#define MPCQP_DISC_EULER 0 /* X+ = X + delta (A X + B U): the reference, src/mpc.py:117 */
+#define MPCQP_DISC_ZOH 1   /* exact zero-order hold; closed form because A^3 = 0, A^2 B = 0 */
+
+/* element type of x0, r, xdes, mu, u_out, X_out */
+#define MPCQP_DTYPE_F32 0
+#define MPCQP_DTYPE_F64 1
+
+/* arithmetic of the engine (product library; the oracle is always all-f64) */
+#define MPCQP_PREC_F32 0   /* matrix tiles and vectors in f32 */
+#define MPCQP_PREC_MIXED 1 /* matrix tiles f32; structured residuals, refinement and duals in f64 */
+#define MPCQP_PREC_F64 2   /* everything f64 */
+
+/* flags */
+#define MPCQP_FLAG_POLISH 1u     /* active-set polish after ADMM (OSQP's `polish`; the reference leaves it off) */
+#define MPCQP_FLAG_WARM_START 2u /* keep (u, z, y) per batch slot between calls (src/mpc.py:270-271 is primal-only) */
+
+/*
+ * Problem + solver configuration.  POD, versioned by its leading `size` field (set to sizeof(MpcQpConfig)).
+ * mpcqp_default_config() fills the Lite3 constants hard-coded in the reference and the engine defaults.
+ */
+typedef struct MpcQpConfig {
+  uint32_t size;        /* sizeof(MpcQpConfig) */
+  int32_t N;            /* horizon, params['N'] (src/mpc.py:30); engine supports 10 and 20 */
+  double delta;         /* params['world_time_step'] (src/mpc.py:31) */
+  double m;             /* 8.885 (src/mpc.py:71) */
+  double Ibody_inv[3];  /* diag(1/0.24, 1, 1) (src/mpc.py:73-76) */
+  double w[13];         /* state weights (src/mpc.py:122-134) */
+  double alpha;         /* force weight; 0.0 in the reference (src/mpc.py:121) */
+  double f_min, f_max;  /* 3, 100 (src/mpc.py:45-46) */
+  int32_t disc;         /* MPCQP_DISC_* */
+  int32_t dtype;        /* MPCQP_DTYPE_* of the caller's buffers */
+  int32_t precision;    /* MPCQP_PREC_* */
+  uint32_t flags;       /* MPCQP_FLAG_* */
+  double rho;           /* ADMM penalty on the constraint rows */
+  double sigma;         /* ADMM proximal weight on u */
+  double relax;         /* over-relaxation in (0,2) */
+  int32_t max_iter;     /* ADMM iteration cap K */
+  int32_t check_every;  /* residual / polish check period (iterations) */
+  double eps_abs, eps_rel;
+  int32_t polish_max;   /* active-set refinement steps per polish attempt */
+  int32_t device;       /* HIP device ordinal (product library) */
+} MpcQpConfig;
+
+typedef struct mpcqp_engine* mpcqp_handle;
+
+uint32_t mpcqp_version(void);
+
+/* Fill *cfg with the reference's constants (N=10, delta=0.03 of the benchmark configs) and engine defaults. */
+int mpcqp_default_config(MpcQpConfig* cfg);
+
+int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out);
+int mpcqp_destroy(mpcqp_handle h);
+
+/*
+ * Solve B independent QPs.  Layouts (row-major, batch outermost; T = cfg.dtype):
+ *   x0      T  [B,13]        x0_param  (src/mpc.py:61,189-198,242): [rpy(rotvec), com, omega, v, g]
+ *   r       T  [B,N,4,3]     foot - com lever arms, legs FL,FR,HL,HR; replaces r1..r4_skew (src/mpc.py:80-83,
+ *                            218-246): the skew matrices (src/utils.py:43-56) are expanded inside the engine
+ *   contact u8 [B,N,4]       1 = stance; swing_param = 1 - contact (src/mpc.py:248-254)
+ *   xdes    T  [B,N+1,13]    x_des (src/mpc.py:119,202-214,255)
+ *   mu      T  [B]           friction coefficient, params['mu'] (src/mpc.py:33)
+ *   u_out   T  [B,N,12]      sol.value(U) (src/mpc.py:267-268), stage-major, legs FL,FR,HL,HR x (fx,fy,fz)
+ *   X_out   T  [B,N+1,13]    sol.value(X) (src/mpc.py:265-266); may be NULL
+ *   status  i32[B]           MPCQP_STATUS_*
+ *   iters   i32[B]           ADMM iterations used (+ 1000 * polish refinement steps)
+ *   res     f32[B,2]         final primal / dual residual (inf-norm); may be NULL
+ * `stream` is a hipStream_t (product) or ignored (oracle).  Asynchronous on the stream; the caller owns all
+ * buffers; no allocation happens after the first call at a given B.
+ */
+int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, const uint8_t* contact,
+                      const void* xdes, const void* mu, void* u_out, void* X_out, int32_t* status,
+                      int32_t* iters, float* res, void* stream);
+
+/* Duration in milliseconds of the most recent solve_batch's kernel(s), measured with HIP events recorded on
+ * `stream` around the launch; blocks until that work has finished.  Oracle: wall time of the call. */
+int mpcqp_last_kernel_ms(mpcqp_handle h, float* ms);
+
+const char* mpcqp_last_error(mpcqp_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCQP_H_ */

@@ -1,0 +1,164 @@
+"""ctypes binding of the C-ABI declared in include/mpcqp.h.
+
+The product path loads ``csrc/libmpcqp.so`` (hand-written HIP for gfx950) and nothing else: if that library is
+missing or cannot be loaded, importing the engine raises -- there is no CPU fallback.  The binding itself is
+generic over the library path because the CPU checker under ``oracle/`` exports the same symbols with host
+pointers; only tests / smoke / bench's cpu_baseline leg ever pass that path in.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int32, c_int64, c_uint32, c_void_p
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_LIB = os.path.join(_PKG_DIR, "csrc", "libmpcqp.so")
+
+# include/mpcqp.h constants
+STATUS_UNSOLVED, STATUS_SOLVED_POLISHED, STATUS_SOLVED_ADMM, STATUS_MAX_ITER, STATUS_NONFINITE = 0, 1, 2, 3, -1
+DISC_EULER, DISC_ZOH = 0, 1
+DTYPE_F32, DTYPE_F64 = 0, 1
+PREC_F32, PREC_MIXED, PREC_F64 = 0, 1, 2
+FLAG_POLISH, FLAG_WARM_START = 1, 2
+
+EXPORTED_SYMBOLS = (
+    "mpcqp_version", "mpcqp_default_config", "mpcqp_create", "mpcqp_destroy", "mpcqp_solve_batch",
+    "mpcqp_last_kernel_ms", "mpcqp_last_error",
+)
+
+
+class MpcQpConfig(ctypes.Structure):
+    """Mirror of ``struct MpcQpConfig`` (include/mpcqp.h)."""
+    _fields_ = [
+        ("size", c_uint32), ("N", c_int32), ("delta", c_double), ("m", c_double),
+        ("Ibody_inv", c_double * 3), ("w", c_double * 13), ("alpha", c_double),
+        ("f_min", c_double), ("f_max", c_double), ("disc", c_int32), ("dtype", c_int32),
+        ("precision", c_int32), ("flags", c_uint32), ("rho", c_double), ("sigma", c_double),
+        ("relax", c_double), ("max_iter", c_int32), ("check_every", c_int32),
+        ("eps_abs", c_double), ("eps_rel", c_double), ("polish_max", c_int32), ("device", c_int32),
+    ]
+
+    def as_dict(self):
+        out = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            out[name] = list(v) if hasattr(v, "__len__") else v
+        return out
+
+
+class MpcQpError(RuntimeError):
+    pass
+
+
+class Library:
+    """A loaded shared object exporting the mpcqp C-ABI."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise MpcQpError(f"mpcqp library not found: {path} (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+        self.path = path
+        self.lib = ctypes.CDLL(path)
+        L = self.lib
+        L.mpcqp_version.restype = c_uint32
+        L.mpcqp_default_config.argtypes = [ctypes.POINTER(MpcQpConfig)]
+        L.mpcqp_default_config.restype = c_int32
+        L.mpcqp_create.argtypes = [ctypes.POINTER(MpcQpConfig), ctypes.POINTER(c_void_p)]
+        L.mpcqp_create.restype = c_int32
+        L.mpcqp_destroy.argtypes = [c_void_p]
+        L.mpcqp_destroy.restype = c_int32
+        L.mpcqp_solve_batch.argtypes = [c_void_p, c_int64] + [c_void_p] * 11
+        L.mpcqp_solve_batch.restype = c_int32
+        L.mpcqp_last_kernel_ms.argtypes = [c_void_p, ctypes.POINTER(c_float)]
+        L.mpcqp_last_kernel_ms.restype = c_int32
+        L.mpcqp_last_error.argtypes = [c_void_p]
+        L.mpcqp_last_error.restype = c_char_p
+
+    def version(self) -> int:
+        return int(self.lib.mpcqp_version())
+
+    def default_config(self, **overrides) -> MpcQpConfig:
+        cfg = MpcQpConfig()
+        rc = self.lib.mpcqp_default_config(ctypes.byref(cfg))
+        if rc != 0:
+            raise MpcQpError(f"mpcqp_default_config failed: {rc}")
+        for k, v in overrides.items():
+            if k in ("w", "Ibody_inv"):
+                arr = getattr(cfg, k)
+                for i, x in enumerate(v):
+                    arr[i] = float(x)
+            else:
+                if not hasattr(cfg, k):
+                    raise AttributeError(f"MpcQpConfig has no field {k!r}")
+                setattr(cfg, k, v)
+        return cfg
+
+
+class Engine:
+    """One handle = one configuration on one device / stream.  Not thread-safe (include/mpcqp.h)."""
+
+    def __init__(self, library: Library, cfg: MpcQpConfig):
+        self.library = library
+        self.cfg = cfg
+        self._h = c_void_p()
+        rc = library.lib.mpcqp_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc != 0:
+            raise MpcQpError(f"mpcqp_create failed with code {rc}")
+
+    def close(self):
+        if self._h:
+            self.library.lib.mpcqp_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self) -> str:
+        return (self.library.lib.mpcqp_last_error(self._h) or b"").decode()
+
+    def solve_batch_ptr(self, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, stream=0):
+        """Raw call: every argument is an integer address (device memory for the product library)."""
+        rc = self.library.lib.mpcqp_solve_batch(self._h, int(B), x0, r, contact, xdes, mu, u_out, X_out or None,
+                                                status, iters, res or None, stream or None)
+        if rc != 0:
+            raise MpcQpError(f"mpcqp_solve_batch failed with code {rc}: {self.last_error()}")
+
+    def last_kernel_ms(self) -> float:
+        ms = c_float()
+        rc = self.library.lib.mpcqp_last_kernel_ms(self._h, ctypes.byref(ms))
+        if rc != 0:
+            raise MpcQpError(f"mpcqp_last_kernel_ms failed with code {rc}: {self.last_error()}")
+        return float(ms.value)
+
+    # host-pointer convenience (numpy); valid for libraries that take host memory
+    def solve_batch_host(self, x0, r, contact, xdes, mu, want_X=True):
+        N = self.cfg.N
+        ft = np.float64 if self.cfg.dtype == DTYPE_F64 else np.float32
+        x0 = np.ascontiguousarray(x0, dtype=ft); r = np.ascontiguousarray(r, dtype=ft)
+        xdes = np.ascontiguousarray(xdes, dtype=ft); mu = np.ascontiguousarray(mu, dtype=ft)
+        contact = np.ascontiguousarray(contact, dtype=np.uint8)
+        B = x0.shape[0]
+        assert x0.shape == (B, 13) and r.shape == (B, N, 4, 3) and contact.shape == (B, N, 4)
+        assert xdes.shape == (B, N + 1, 13) and mu.shape == (B,)
+        u = np.zeros((B, N, 12), ft)
+        X = np.zeros((B, N + 1, 13), ft) if want_X else None
+        status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); res = np.zeros((B, 2), np.float32)
+        self.solve_batch_ptr(B, x0.ctypes.data, r.ctypes.data, contact.ctypes.data, xdes.ctypes.data, mu.ctypes.data,
+                             u.ctypes.data, X.ctypes.data if want_X else None, status.ctypes.data, iters.ctypes.data,
+                             res.ctypes.data)
+        return {"u": u, "X": X, "status": status, "iters": iters, "res": res}
+
+
+_product = None
+
+
+def product_library() -> Library:
+    """The HIP engine.  Raises (loudly) when the extension has not been built -- never falls back."""
+    global _product
+    if _product is None:
+        _product = Library(PRODUCT_LIB)
+    return _product

@@ -1,0 +1,118 @@
+"""Synthetic Lite3 QP batches for the benchmark configurations.
+
+Produces the operator tuple that crosses into the solver -- the batched, compact form of the seven
+``opt.set_value`` parameters of the reference (src/mpc.py:242-255):
+
+    x0[B,13]  r[B,N,4,3]  contact[B,N,4] (u8, 1 = stance)  xdes[B,N+1,13]  mu[B]
+
+Pure numpy (host side); the arrays are uploaded once and stay resident in HBM for the timed region.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# Lite3 constants (src/main.py:32-33, src/mpc.py:45-46,71-76) and nominal stance geometry taken from the
+# reference's committed log at tick 0 (FEET POS.actual[0] - com[0]); SURVEY.md section 8(d).
+G_ACC = -9.81
+H_COM = 0.285
+FOOT_Z = 0.01713
+NOMINAL_FEET = np.array([
+    [0.11648, 0.16078, -0.26780],    # FL
+    [0.11648, -0.16022, -0.26780],   # FR
+    [-0.23252, 0.16078, -0.26780],   # HL
+    [-0.23252, -0.16022, -0.26780],  # HR
+])
+V_REF_BODY = np.array([0.18, 0.0, 0.0])          # src/main.py:43
+SS_TICKS, DS_TICKS = 10, 5                       # src/main.py:35-36
+
+# first_swing encodings as the reference's planner uses them (1 = stance during the step's ss phase,
+# src/footstep_planner.py:11-13,159-177): the pattern alternates with its complement every step.
+GAITS = {
+    "trot": (1, 0, 0, 1),
+    "pronk": (0, 0, 0, 0),
+    "amble": (1, 0, 1, 0),
+    "gallop": (0, 0, 1, 1),          # the committed default, "pseudo-galloping" (src/main.py:39)
+}
+
+
+def contact_schedule(gait_ids, t0, N, gaits=None):
+    """contact[B,N,4]: phase semantics of src/footstep_planner.py:239-246 for an endless two-beat gait.
+
+    A step lasts ss+ds ticks; during the first ss ticks the step's feet_id applies, then all four feet
+    are in stance.  feet_id alternates with its complement each step (src/footstep_planner.py:176-177).
+    gait_ids[B] index into `gaits` (list of 4-tuples); t0[B] is the tick offset of stage 0.
+    """
+    gaits = np.asarray(gaits if gaits is not None else list(GAITS.values()), dtype=np.uint8)
+    B = len(t0)
+    t = np.asarray(t0)[:, None] + np.arange(N)[None, :]               # [B,N]
+    step = t // (SS_TICKS + DS_TICKS)
+    in_step = t % (SS_TICKS + DS_TICKS)
+    base = gaits[np.asarray(gait_ids)]                                # [B,4]
+    fid = np.where((step % 2 == 0)[:, :, None], base[:, None, :], 1 - base[:, None, :])
+    contact = np.where((in_step < SS_TICKS)[:, :, None], fid, 1).astype(np.uint8)
+    assert contact.shape == (B, N, 4)
+    return contact
+
+
+def make_batch(B, N=10, delta=0.03, seed=20250808, gait_names=("trot",), mus=(1.0,), dtype=np.float64):
+    """State distribution of SURVEY.md section 8(d) config 2 (and 3-5 via gait_names / mus / N / seed)."""
+    rng = np.random.default_rng(seed)
+    roll = rng.uniform(-0.1, 0.1, B)
+    pitch = rng.uniform(-0.1, 0.1, B)
+    yaw = rng.uniform(-np.pi, np.pi, B)
+    com = np.array([0.0, 0.0, H_COM])[None, :] + rng.normal(0.0, 0.02, (B, 3)) * np.array([1.0, 1.0, 0.5])
+    omega = rng.normal(0.0, 0.2, (B, 3))
+    c, s = np.cos(yaw), np.sin(yaw)
+    v_ref = np.stack([c * V_REF_BODY[0] - s * V_REF_BODY[1], s * V_REF_BODY[0] + c * V_REF_BODY[1],
+                      np.full(B, V_REF_BODY[2])], axis=1)
+    v = v_ref + rng.normal(0.0, 0.1, (B, 3))
+    feet_xy = np.stack([c[:, None] * NOMINAL_FEET[None, :, 0] - s[:, None] * NOMINAL_FEET[None, :, 1],
+                        s[:, None] * NOMINAL_FEET[None, :, 0] + c[:, None] * NOMINAL_FEET[None, :, 1]], axis=2)
+    feet = np.concatenate([com[:, None, :2] + feet_xy + rng.normal(0.0, 0.01, (B, 4, 2)),
+                           np.full((B, 4, 1), FOOT_Z)], axis=2)      # [B,4,3] world, fixed over the horizon
+    t0 = rng.integers(0, 30, B)
+    gait_ids = rng.integers(0, len(gait_names), B)
+    mu = np.asarray(mus, float)[rng.integers(0, len(mus), B)]
+
+    x0 = np.concatenate([roll[:, None], pitch[:, None], yaw[:, None], com, omega, v,
+                         np.full((B, 1), G_ACC)], axis=1)            # src/mpc.py:189-198
+    # x_des, src/mpc.py:202-214 with roll0 = pitch0 = 0, omega_ref = 0, yaw_start = yaw, com_start = (x,y,h)
+    k = np.arange(N + 1)[None, :, None]
+    com_start = np.concatenate([com[:, :2], np.full((B, 1), H_COM)], axis=1)
+    xdes = np.zeros((B, N + 1, 13))
+    xdes[:, :, 2] = yaw[:, None]
+    xdes[:, :, 3:6] = com_start[:, None, :] + k * delta * v_ref[:, None, :]
+    xdes[:, :, 9:12] = v_ref[:, None, :]
+    xdes[:, :, 12] = G_ACC
+    # lever arms, src/mpc.py:218-239: stage 0 from the measured com, stage k>=1 from the reference com
+    r = feet[:, None, :, :] - xdes[:, :N, None, 3:6]
+    r[:, 0] = feet - com[:, None, :]
+    contact = contact_schedule(gait_ids, t0, N, gaits=[GAITS[g] for g in gait_names])
+    return {
+        "x0": np.ascontiguousarray(x0, dtype=dtype),
+        "r": np.ascontiguousarray(r, dtype=dtype),
+        "contact": np.ascontiguousarray(contact, dtype=np.uint8),
+        "xdes": np.ascontiguousarray(xdes, dtype=dtype),
+        "mu": np.ascontiguousarray(mu, dtype=dtype),
+        "gait_ids": gait_ids, "t0": t0,
+    }
+
+
+def config2(B=1024, dtype=np.float64):
+    """B=1024 randomised states, trot, N=10, delta=0.03, mu=1 (seed 20250808)."""
+    return make_batch(B, 10, 0.03, 20250808, ("trot",), (1.0,), dtype)
+
+
+def config3(B=4096, dtype=np.float64):
+    """B=4096 mixed gaits + friction sweep, N=10 (seed 20250809) -- the configuration the metric is quoted on."""
+    return make_batch(B, 10, 0.03, 20250809, ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0), dtype)
+
+
+def config4(B=65536, dtype=np.float64):
+    """B=65536 of the config-3 distribution (seed 20250810), sharded contiguously across ranks."""
+    return make_batch(B, 10, 0.03, 20250810, ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0), dtype)
+
+
+def config5(B=4096, dtype=np.float64):
+    """B=4096, N=20 (seed 20250811)."""
+    return make_batch(B, 20, 0.03, 20250811, ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0), dtype)
