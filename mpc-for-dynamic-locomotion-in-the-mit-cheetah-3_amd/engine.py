@@ -1,0 +1,78 @@
+"""Batched solve surface over the HIP engine (torch is used only for device memory and streams).
+
+``MPCBatch.solve_batch`` is the B>1 counterpart of the reference's ``MPC.solve`` (src/mpc.py:176-303): it
+takes the operator tuple that the reference pushes into CasADi with seven ``opt.set_value`` calls
+(src/mpc.py:242-255) in compact batched form and returns ``sol.value(U)`` / ``sol.value(X)``
+(src/mpc.py:265-268) for every instance, plus per-QP status / iteration / residual outputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class MPCBatch:
+    """One engine handle on one GPU.  All tensors live on ``cuda:<device>``; nothing is copied to the host."""
+
+    def __init__(self, N=10, delta=0.03, device=0, io_dtype="f32", precision="mixed", **overrides):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _capi.MpcQpError("MPCBatch needs a GPU: the mpcqp engine has no CPU path")
+        lib = _capi.product_library()
+        cfg = lib.default_config(N=N, delta=delta, device=device,
+                                 dtype={"f32": _capi.DTYPE_F32, "f64": _capi.DTYPE_F64}[io_dtype],
+                                 precision={"f32": _capi.PREC_F32, "mixed": _capi.PREC_MIXED, "f64": _capi.PREC_F64}[precision],
+                                 **overrides)
+        self.N, self.delta = N, delta
+        self.device = torch.device("cuda", device)
+        self.tdtype = torch.float32 if io_dtype == "f32" else torch.float64
+        self.engine = _capi.Engine(lib, cfg)
+        self.cfg = cfg
+        self._out = {}
+
+    def upload(self, batch):
+        """Host numpy batch (mpcqp.synth layout) -> resident device tensors."""
+        torch = _torch()
+        f = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=self.tdtype).to(self.device).contiguous()
+        return {"x0": f(batch["x0"]), "r": f(batch["r"]), "xdes": f(batch["xdes"]), "mu": f(batch["mu"]),
+                "contact": torch.as_tensor(np.ascontiguousarray(batch["contact"], dtype=np.uint8)).to(self.device).contiguous()}
+
+    def _outputs(self, B, want_X):
+        torch = _torch()
+        key = (B, want_X)
+        if key not in self._out:   # allocated once per batch size, reused afterwards
+            N = self.N
+            self._out[key] = {
+                "u": torch.empty((B, N, 12), dtype=self.tdtype, device=self.device),
+                "X": torch.empty((B, N + 1, 13), dtype=self.tdtype, device=self.device) if want_X else None,
+                "status": torch.empty(B, dtype=torch.int32, device=self.device),
+                "iters": torch.empty(B, dtype=torch.int32, device=self.device),
+                "res": torch.empty((B, 2), dtype=torch.float32, device=self.device),
+            }
+        return self._out[key]
+
+    def solve_batch(self, x0, r, contact, xdes, mu, want_X=False, stream=None):
+        """Asynchronous on ``stream`` (default: torch's current stream); results valid after a stream sync."""
+        torch = _torch()
+        N = self.N
+        B = int(x0.shape[0])
+        for t, shape, dt in ((x0, (B, 13), self.tdtype), (r, (B, N, 4, 3), self.tdtype), (contact, (B, N, 4), torch.uint8),
+                             (xdes, (B, N + 1, 13), self.tdtype), (mu, (B,), self.tdtype)):
+            if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"operand mismatch: expected {shape} {dt} contiguous on {self.device}, got "
+                                 f"{tuple(t.shape)} {t.dtype} on {t.device}")
+        out = self._outputs(B, want_X)
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self.engine.solve_batch_ptr(B, x0.data_ptr(), r.data_ptr(), contact.data_ptr(), xdes.data_ptr(), mu.data_ptr(),
+                                    out["u"].data_ptr(), out["X"].data_ptr() if want_X else None, out["status"].data_ptr(),
+                                    out["iters"].data_ptr(), out["res"].data_ptr(), st.cuda_stream)
+        return out
+
+    def last_kernel_ms(self):
+        return self.engine.last_kernel_ms()
