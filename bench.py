@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Headline benchmark: QP solves/sec (horizon=10, 4-contact Lite3) at batch=4096 per GPU.
+
+One "step" = one pass of the hot path (raw operator tuple -> solved ground-reaction forces: model build,
+discretisation, condensing, matrix inversion, ADMM, polish) over one resident batch of 4096 synthetic QPs
+(mixed gaits + friction sweep, seed 20250809 + rank).  Inputs and outputs stay
+in HBM for the whole timed region.  N>1: the batch axis is sharded, one rank per GPU, no data-path collective
+(weak scaling: 4096 QPs per GPU); `--allgather` adds the optional RCCL all-gather of stage-0 GRFs.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the solve kernel against the fp32 matrix/vector peak with the
+ALGORITHMIC flop count of SURVEY.md section 8(d); `cpu_baseline` times the fp64 CPU oracle on a bounded sample
+of the same workload on the host cores (a reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+import mpcqp  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0        # HBM3E spec (6290 measured float4 copy)
+
+
+def algorithmic_flops(N, K):
+    """n^2 s + n^3/3 + K (2 n^2 + 60 n), n = 12N, s = 13N."""
+    n, s = 12 * N, 13 * N
+    return n * n * s + n ** 3 / 3.0 + K * (2 * n * n + 60 * n)
+
+
+def algorithmic_bytes(N, elt=4):
+    """operator tuple in + forces/status out (fp32: 1636 B at N=10)."""
+    return (13 + 12 * N + 13 * (N + 1) + 1) * elt + 4 * N + 12 * N * elt + 8
+
+
+def cpu_baseline(batch, cfg_kw, sample):
+    """fp64 CPU oracle (oracle/, OpenMP over the batch) on the first `sample` QPs; same solver settings."""
+    path = os.path.join(REPO, "oracle", "libmpcqp_oracle.so")
+    if not os.path.exists(path):
+        return None
+    lib = mpcqp.Library(path)
+    eng = mpcqp.Engine(lib, lib.default_config(**cfg_kw))
+    sub = {k: batch[k][:sample] for k in ("x0", "r", "contact", "xdes", "mu")}
+    t0 = time.perf_counter()
+    out = eng.solve_batch_host(sub["x0"], sub["r"], sub["contact"], sub["xdes"], sub["mu"], want_X=False)
+    dt = time.perf_counter() - t0
+    st = out["status"]
+    return {"value": sample / dt, "unit": "QP solves/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"first {sample} QPs of the same batch, fp64 condensed OSQP-style ADMM + polish, OpenMP over the batch, "
+                      f"{dt:.1f} s wall; solved fraction {float(((st == 1) | (st == 2)).mean()):.3f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4096, help="QPs per GPU")
+    ap.add_argument("--precision", default="mixed", choices=["f32", "mixed", "f64"])
+    ap.add_argument("--allgather", action="store_true", help="all-gather stage-0 GRFs over RCCL every step")
+    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    N, delta, B = 10, 0.03, args.batch
+    gaits, mus = ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0)
+    batch = mpcqp.synth.make_batch(B, N, delta, 20250809 + rank, gaits, mus)      # this rank's shard
+    solver = mpcqp.MPCBatch(N=N, delta=delta, device=local_rank, io_dtype="f32", precision=args.precision)
+    dev = solver.upload(batch)
+    gathered = torch.empty((world * B, 12), dtype=torch.float32, device=solver.device) if args.allgather and world > 1 else None
+
+    def step():
+        out = solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], want_X=False)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, out["u"][:, 0, :].contiguous())
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()                       # same stream the engine launches on (torch's current stream)
+    for _ in range(args.steps):
+        out = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps       # average launch duration over the timed region
+    last_ms = solver.last_kernel_ms()                    # engine's own event pair around the last launch
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=solver.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    status = out["status"].cpu().numpy()
+    iters = out["iters"].cpu().numpy()
+    solved = float(((status == 1) | (status == 2)).mean())
+    k_mean = float((iters % 1000).mean())
+    if rank == 0:
+        value = world * B * args.steps / dt
+        flops = algorithmic_flops(N, k_mean)
+        achieved = flops * B / (kernel_ms * 1e-3) / 1e12
+        hbm = algorithmic_bytes(N) * B / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "QP solves/sec (horizon=10, 4-contact Lite3) at batch=4096", "value": value, "unit": "QP solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "mixed": "f32 tiles + f64 residuals", "f64": "f64"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: batch=4096/GPU mixed gaits (trot/pronk/amble/gallop) + mu sweep, horizon=10, "
+                                   "dt=0.03, Lite3 constants, alpha=1e-2, euler", "batch_per_gpu": B, "horizon": N,
+                       "precision": args.precision, "admm_block": int(solver.cfg.check_every), "max_iter": int(solver.cfg.max_iter),
+                       "polish": bool(solver.cfg.flags & 1), "allgather": bool(gathered is not None),
+                       "solved_fraction": solved, "admm_iters_mean": k_mean, "polish_steps_mean": float((iters // 1000).mean())},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel": "mpcqp_solve_kernel<float,double,float,10>", "kernel_ms": kernel_ms, "kernel_ms_last_launch": last_ms,
+                         "algorithmic_flops_per_qp": flops,
+                         "hbm": {"achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS,
+                                 "algorithmic_bytes_per_qp": algorithmic_bytes(N), "note": "non-binding roof (SURVEY 8d)"}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(batch, dict(N=N, delta=delta, rho=solver.cfg.rho, sigma=solver.cfg.sigma, relax=solver.cfg.relax,
+                                          max_iter=int(solver.cfg.max_iter), check_every=int(solver.cfg.check_every),
+                                          eps_abs=solver.cfg.eps_abs, eps_rel=solver.cfg.eps_rel,
+                                          polish_max=int(solver.cfg.polish_max), flags=int(solver.cfg.flags)),
+                              min(args.cpu_sample, B))
+            if cb:
+                line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

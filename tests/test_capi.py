@@ -1,0 +1,70 @@
+"""The C-ABI libraries load and export every symbol include/mpcqp.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import mpcqp
+from conftest import REPO, _have_gpu
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(REPO, "include", "mpcqp.h")).read()
+    return sorted(set(re.findall(r"\b(mpcqp_[a-z_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_match_binding():
+    assert set(_declared_symbols()) == set(mpcqp._capi.EXPORTED_SYMBOLS)
+
+
+def test_product_library_exports_all_symbols():
+    lib = mpcqp.product_library()            # fails loudly if the HIP library has not been built
+    for sym in _declared_symbols():
+        assert hasattr(lib.lib, sym), sym
+    assert lib.version() == 0x00010000
+
+
+def test_oracle_exports_same_symbols(oracle_lib):
+    for sym in _declared_symbols():
+        assert hasattr(oracle_lib.lib, sym), sym
+
+
+def test_config_struct_layout_and_defaults(oracle_lib):
+    plib = mpcqp.product_library()
+    for lib in (plib, oracle_lib):
+        cfg = lib.default_config()
+        assert cfg.size == ctypes.sizeof(mpcqp.MpcQpConfig)
+        # Lite3 constants hard-coded in the reference (src/mpc.py:45-46,71-76,122-134)
+        assert cfg.N == 10 and abs(cfg.delta - 0.03) < 1e-15
+        assert cfg.m == 8.885 and list(cfg.Ibody_inv) == [1 / 0.24, 1.0, 1.0]
+        assert list(cfg.w) == [1e4, 2.7e4, 1e4, 2.7e5, 2.7e5, 2.7e5, 1e4, 1e4, 1e4, 1.6e4, 1.6e4, 1.6e4, 0.0]
+        assert (cfg.f_min, cfg.f_max) == (3.0, 100.0)
+        assert cfg.disc == mpcqp.DISC_EULER
+
+
+def test_product_never_falls_back_to_cpu():
+    """Without a gfx950 device the product library refuses to create an engine (MPCQP_ENODEV), it does not emulate."""
+    if _have_gpu():
+        pytest.skip("GPU present")
+    lib = mpcqp.product_library()
+    with pytest.raises(mpcqp.MpcQpError, match="-4"):
+        mpcqp.Engine(lib, lib.default_config())
+    with pytest.raises(mpcqp.MpcQpError):
+        mpcqp.MPCBatch()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(mpcqp.MpcQpError, match="not found"):
+        mpcqp.Library(str(tmp_path / "libmpcqp.so"))
+
+
+def test_bad_config_rejected(oracle_lib):
+    cfg = oracle_lib.default_config()
+    cfg.size = 8
+    with pytest.raises(mpcqp.MpcQpError):
+        mpcqp.Engine(oracle_lib, cfg)
+    plib = mpcqp.product_library()
+    for kw in (dict(N=7), dict(precision=9), dict(relax=2.5), dict(delta=-1.0), dict(disc=5)):
+        with pytest.raises(mpcqp.MpcQpError, match="-1"):
+            mpcqp.Engine(plib, plib.default_config(**kw))

@@ -1,0 +1,181 @@
+"""Parity of the HIP engine (through the C-ABI) with the CPU oracle.  Floating-point tolerances, all stated here:
+
+* MIXED (fp32 tiles, fp64 residuals -- the benchmarked mode) and F64: per-QP  |u - u_oracle|_inf / |u_oracle|_inf <= 1e-4
+  on the full horizon for every QP the engine reports solved (BASELINE.json target).  Measured ~1e-5 max.
+* F32 (everything fp32): <= 2e-2; fp32 storage of the cost terms alone moves the optimum by ~1e-4..1e-2 because the
+  force-distribution directions are only curved by alpha = 1e-2 against stiff directions of ~3e3 (cond ~1e5).
+* predicted states X: <= 1e-4 absolute (MIXED/F64).
+"""
+import numpy as np
+import pytest
+import torch
+
+import mpcqp
+import qp_spec as S
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = {"mixed": 1e-4, "f64": 1e-4, "f32": 2e-2}
+
+
+def gpu_solve(batch, N=10, delta=0.03, io="f64", precision="mixed", want_X=True, **kw):
+    sol = mpcqp.MPCBatch(N=N, delta=delta, io_dtype=io, precision=precision, **kw)
+    dev = sol.upload(batch)
+    out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], want_X=want_X)
+    torch.cuda.synchronize()
+    res = {k: (v.cpu().numpy() if v is not None else None) for k, v in out.items()}
+    res["ms"] = sol.last_kernel_ms()
+    return res
+
+
+def solved(st):
+    return (st == 1) | (st == 2)
+
+
+@pytest.mark.parametrize("precision,io", [("mixed", "f32"), ("mixed", "f64"), ("f64", "f64"), ("f32", "f32")])
+def test_config2_trot_parity(oracle_solve, precision, io):
+    b = mpcqp.synth.config2(256)
+    ref = oracle_solve(b)
+    out = gpu_solve(b, io=io, precision=precision)
+    ok = solved(out["status"])
+    assert ok.mean() >= 0.97
+    e = rel_err(out["u"], ref["u"])
+    assert e[ok].max() <= TOL[precision], (precision, io, e[ok].max())
+    if precision != "f32":
+        assert np.abs(out["X"][ok] - ref["X"][ok]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("precision", ["mixed", "f64"])
+def test_config3_mixed_gaits_parity(oracle_solve, precision):
+    b = mpcqp.synth.config3(512)
+    ref = oracle_solve(b)
+    out = gpu_solve(b, io="f32", precision=precision)
+    ok = solved(out["status"])
+    assert ok.mean() >= 0.97
+    e = rel_err(out["u"], ref["u"])
+    assert e[ok].max() <= TOL[precision]
+    # swing legs carry exactly zero force (src/mpc.py:139-144), on every QP, solved or not
+    swing = np.repeat(b["contact"] == 0, 3, axis=2).reshape(len(e), 10, 12)
+    assert np.all(out["u"][swing] == 0)
+
+
+def test_config5_horizon20_parity(oracle_solve):
+    b = mpcqp.synth.config5(128)
+    ref = oracle_solve(b, N=20)
+    out = gpu_solve(b, N=20, io="f32", precision="mixed")
+    ok = solved(out["status"])
+    assert ok.mean() >= 0.95
+    assert rel_err(out["u"], ref["u"])[ok].max() <= 1e-4
+
+
+def test_zoh_discretisation_parity(oracle_solve):
+    b = mpcqp.synth.config3(128)
+    ref = oracle_solve(b, disc=mpcqp.DISC_ZOH)
+    out = gpu_solve(b, disc=mpcqp.DISC_ZOH)
+    ok = solved(out["status"])
+    assert ok.mean() >= 0.97 and rel_err(out["u"], ref["u"])[ok].max() <= 1e-4
+    # and it is a different problem from Euler: the check above is not vacuous
+    ref_e = oracle_solve(b)
+    assert rel_err(ref["u"], ref_e["u"]).max() > 1e-3
+
+
+def test_golden_log_ticks(golden):
+    """QPs rebuilt from the reference's committed run log (delta = 0.01, the logged gait), N = 10 and 20,
+    against the committed oracle optima."""
+    q, opt = golden["qp_inputs"], golden["qp_optima"]
+    for N in (10, 20):
+        b = {"x0": q[f"N{N}_x0"], "r": q[f"N{N}_r"], "contact": q[f"N{N}_contact"], "xdes": q[f"N{N}_xdes"],
+             "mu": np.full(len(q["ticks"]), float(q["mu"]))}
+        out = gpu_solve(b, N=N, delta=float(q["delta"]), precision="mixed", max_iter=2000)
+        ok = solved(out["status"])
+        assert ok.sum() >= len(ok) - 1
+        assert rel_err(out["u"], opt[f"N{N}_a1e-2_u"])[ok].max() <= 1e-4
+        assert np.abs(out["X"][ok] - opt[f"N{N}_a1e-2_X"][ok]).max() <= 1e-4
+
+
+def test_alpha0_reference_cost_unique_quantities(golden):
+    """The reference's own cost (alpha = 0): GRFs are not unique; objective and predicted states are.
+    ADMM only (polish needs alpha > 0); tolerance: objective 1e-4 relative, states 2e-3 absolute at K = 4000."""
+    q, opt = golden["qp_inputs"], golden["qp_optima"]
+    N = 10
+    b = {"x0": q[f"N{N}_x0"], "r": q[f"N{N}_r"], "contact": q[f"N{N}_contact"], "xdes": q[f"N{N}_xdes"],
+         "mu": np.full(len(q["ticks"]), float(q["mu"]))}
+    out = gpu_solve(b, N=N, delta=float(q["delta"]), precision="f64", alpha=0.0, max_iter=4000, eps_abs=1e-7, eps_rel=1e-7)
+    cfg = S.QPConfig(N=N, delta=float(q["delta"]), alpha=0.0)
+    for i in range(len(b["mu"])):
+        J = S.objective(out["X"][i], out["u"][i], b["xdes"][i], cfg)
+        assert abs(J - opt["N10_a0_J"][i]) <= 1e-4 * max(1.0, abs(opt["N10_a0_J"][i]))
+        assert np.abs(out["X"][i] - opt["N10_a0_X"][i]).max() <= 2e-3
+
+
+def test_admm_only_converges_to_oracle(oracle_solve):
+    """No polish: plain ADMM in f64 run long enough reaches the oracle (the polish is an accelerator, not a crutch)."""
+    b = mpcqp.synth.config2(32)
+    ref = oracle_solve(b)
+    out = gpu_solve(b, precision="f64", flags=0, max_iter=20000, check_every=100, eps_abs=1e-9, eps_rel=1e-9)
+    assert np.all(out["status"] == 2)
+    assert rel_err(out["u"], ref["u"]).max() <= 1e-4
+
+
+def test_full_size_properties():
+    """BASELINE batch (4096): size-independent properties instead of a 4096-QP oracle run -- feasibility of every
+    constraint of src/mpc.py:138-173, zero swing forces, dynamics consistency of X_out, determinism."""
+    b = mpcqp.synth.config3(4096)
+    out = gpu_solve(b, io="f32", precision="mixed")
+    out2 = gpu_solve(b, io="f32", precision="mixed")
+    assert np.array_equal(out["u"], out2["u"]) and np.array_equal(out["status"], out2["status"])   # bitwise repeatable
+    ok = solved(out["status"])
+    assert ok.mean() >= 0.97
+    u = out["u"].astype(np.float64).reshape(4096, 10, 4, 3)
+    c = b["contact"].astype(bool)
+    mu = b["mu"][:, None, None]
+    assert np.all(u[~c] == 0)
+    fz = u[..., 2]
+    tol = 1e-3
+    assert np.all(fz[c & ok[:, None, None]] >= 3 - tol) and np.all(fz[c & ok[:, None, None]] <= 100 + tol)
+    assert np.all((np.abs(u[..., 0]) <= mu * fz + tol)[ok]) and np.all((np.abs(u[..., 1]) <= mu * fz + tol)[ok])
+    cfg = S.QPConfig(N=10, delta=0.03, alpha=1e-2)
+    for i in range(0, 4096, 512):
+        X = S.predict_states(b["x0"][i], u[i].reshape(-1), b["r"][i], b["contact"][i], cfg)
+        assert np.abs(X - out["X"][i]).max() <= 2e-4        # fp32 outputs
+
+
+def test_edge_cases(oracle_solve):
+    b = mpcqp.synth.config3(8)
+    # batch of one
+    one = {k: v[:1] for k, v in b.items()}
+    ref = oracle_solve(one)
+    out = gpu_solve(one)
+    assert solved(out["status"]).all() and rel_err(out["u"], ref["u"]).max() <= 1e-4
+    # pronk flight phase: every leg in swing at every stage -> all forces exactly 0, status solved
+    fl = {k: v[:2].copy() for k, v in b.items()}
+    fl["contact"][:] = 0
+    out = gpu_solve(fl)
+    assert np.all(out["u"] == 0) and solved(out["status"]).all()
+    # non-finite input: status -1, zero outputs, neighbours unaffected
+    bad = {k: v.copy() for k, v in b.items()}
+    bad["r"][3, 2, 1, 0] = np.inf
+    out = gpu_solve(bad)
+    ref = oracle_solve(b)
+    assert out["status"][3] == -1 and np.all(out["u"][3] == 0)
+    keep = np.arange(8) != 3
+    assert rel_err(out["u"][keep], ref["u"][keep]).max() <= 1e-4
+    # empty batch is a no-op
+    sol = mpcqp.MPCBatch()
+    e = {k: torch.empty((0,) + s, dtype=dt, device="cuda") for k, s, dt in
+         (("x0", (13,), torch.float32), ("r", (10, 4, 3), torch.float32), ("contact", (10, 4), torch.uint8),
+          ("xdes", (11, 13), torch.float32), ("mu", (), torch.float32))}
+    o = sol.solve_batch(e["x0"], e["r"], e["contact"], e["xdes"], e["mu"])
+    torch.cuda.synchronize()
+    assert o["u"].shape == (0, 10, 12)
+
+
+def test_operand_validation():
+    sol = mpcqp.MPCBatch()
+    b = sol.upload(mpcqp.synth.config2(4))
+    with pytest.raises(ValueError):
+        sol.solve_batch(b["x0"][:, :12].contiguous(), b["r"], b["contact"], b["xdes"], b["mu"])
+    with pytest.raises(ValueError):
+        sol.solve_batch(b["x0"].double(), b["r"], b["contact"], b["xdes"], b["mu"])
+    with pytest.raises(ValueError):
+        sol.solve_batch(b["x0"].cpu(), b["r"], b["contact"], b["xdes"], b["mu"])

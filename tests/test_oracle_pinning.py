@@ -1,0 +1,158 @@
+"""Pins the CPU oracle (test infrastructure) before anything is compared with it.
+
+What the reference offers for this path: no tests, no fixtures; one committed run log.
+The log pins the QP *inputs* exactly and the *outputs* only loosely (the logged OSQP answers are unconverged).
+So: (1) the two independent restatements (numpy, literal sparse + condensed; C, literal condensed) must agree;
+(2) every oracle answer must pass an explicit KKT check of the QP src/mpc.py:58-173 defines;
+(3) the model constants are pinned by the logged horizon predictions (Euler dynamics with delta=0.01, m=8.885);
+(4) the oracle's optimum must not be worse than the reference's own logged (unconverged) prediction;
+(5) the committed golden optima are reproduced.
+Solver outputs remain "parity unpinned" against OSQP itself (absent from the image, version unpinned upstream).
+"""
+import numpy as np
+import pytest
+
+import mpcqp
+import qp_spec as S
+from conftest import rel_err
+
+
+def _qp(golden, N, i):
+    q = golden["qp_inputs"]
+    return q[f"N{N}_x0"][i], q[f"N{N}_r"][i], q[f"N{N}_contact"][i], q[f"N{N}_xdes"][i], float(q["mu"])
+
+
+def test_sparse_and_condensed_forms_agree():
+    """The literal multiple-shooting QP of src/mpc.py:58-173 and the condensed form have the same optimum."""
+    b = mpcqp.synth.make_batch(3, N=4, delta=0.03, seed=5, gait_names=("trot", "gallop"), mus=(0.5, 1.0))
+    cfg = S.QPConfig(N=4, delta=0.03, alpha=1e-2)
+    for i in range(3):
+        x0, r, c, xd, mu = b["x0"][i], b["r"][i], b["contact"][i], b["xdes"][i], b["mu"][i]
+        H, g, c0, G, lo, hi, Sx, Su = S.condensed_qp(x0, r, c, xd, mu, cfg)
+        u, z, y, *_ = S.admm_solve(H, g, G, lo, hi, eps=1e-10, max_iter=60000)
+        u, y, ok = S.polish(H, g, G, lo, hi, u, y)
+        assert ok
+        P, q, c0s, Ac, los, his = S.sparse_qp(x0, r, c, xd, mu, cfg)
+        X = S.predict_states(x0, u, r, c, cfg)
+        zs = np.concatenate([X.reshape(-1), u])
+        Az = Ac @ zs
+        assert np.all(Az >= los - 1e-7) and np.all(Az <= his + 1e-7)              # feasible in the literal form
+        Js = 0.5 * zs @ P @ zs + q @ zs + c0s
+        Jc = 0.5 * u @ H @ u + g @ u + c0
+        assert abs(Js - Jc) <= 1e-9 * max(1.0, abs(Jc))
+        assert abs(S.objective(X, u, xd, cfg) - Jc) <= 1e-9 * max(1.0, abs(Jc))
+        # the sparse QP solved on its own (generic ADMM on P,q,Ac) reaches the same objective and states
+        zz, _, _, it, rp, rd = S.admm_solve(P, q, Ac, np.maximum(los, -1e20), np.minimum(his, 1e20), rho=1.0,
+                                            eps=1e-9, max_iter=40000)
+        assert abs((0.5 * zz @ P @ zz + q @ zz + c0s) - Jc) <= 1e-5 * max(1.0, abs(Jc))
+        assert np.abs(zz[:X.size] - X.reshape(-1)).max() <= 1e-4
+
+
+@pytest.mark.parametrize("disc", ["euler", "zoh"])
+def test_c_oracle_matches_numpy_restatement_and_kkt(oracle_solve, disc):
+    b = mpcqp.synth.config3(24)
+    ref = oracle_solve(b, disc={"euler": mpcqp.DISC_EULER, "zoh": mpcqp.DISC_ZOH}[disc])
+    assert np.all(ref["status"] == 1)
+    cfg = S.QPConfig(N=10, delta=0.03, alpha=1e-2, disc=disc)
+    for i in range(24):
+        x0, r, c, xd, mu = b["x0"][i], b["r"][i], b["contact"][i], b["xdes"][i], b["mu"][i]
+        H, g, c0, G, lo, hi, *_ = S.condensed_qp(x0, r, c, xd, mu, cfg)
+        u = ref["u"][i].reshape(-1)
+        # duals by least squares on the active rows, then the explicit KKT certificate
+        Gu = G @ u
+        act = (np.abs(Gu - lo) <= 1e-7 * np.maximum(1, np.abs(lo))) | (np.abs(Gu - hi) <= 1e-7 * np.maximum(1, np.abs(hi)))
+        y = np.zeros(len(lo))
+        if act.any():
+            y[act] = np.linalg.lstsq(G[act].T, -(H @ u + g), rcond=None)[0]
+        k = S.kkt_report(H, g, G, lo, hi, u, y)
+        scale = max(1.0, np.abs(g).max())
+        assert k["stationarity"] <= 1e-7 * scale, k
+        assert k["primal"] <= 1e-7 * max(1.0, np.abs(u).max()), k
+        # predicted states: literal recursion in numpy vs the C oracle's rollout
+        assert np.abs(S.predict_states(x0, u, r, c, cfg) - ref["X"][i]).max() <= 1e-10
+    # numpy solver path agrees with the C solver path
+    for i in range(4):
+        x0, r, c, xd, mu = b["x0"][i], b["r"][i], b["contact"][i], b["xdes"][i], b["mu"][i]
+        H, g, c0, G, lo, hi, *_ = S.condensed_qp(x0, r, c, xd, mu, cfg)
+        u, z, y, *_ = S.admm_solve(H, g, G, lo, hi, eps=1e-10, max_iter=60000)
+        u, y, ok = S.polish(H, g, G, lo, hi, u, y)
+        assert ok and np.abs(u - ref["u"][i].reshape(-1)).max() <= 1e-7
+
+
+def test_log_pins_model_constants(golden):
+    """The logged horizon predictions obey the explicit-Euler SRB model with delta=0.01 and m=8.885
+    (src/mpc.py:71,110-117) to OSQP's slack: p_{k+1} = p_k + delta v_k, and the v_z row with the logged f_z."""
+    L = golden["ref_log"]
+    d = float(L["param_world_time_step"]); g = float(L["param_g"])
+    assert d == 0.01 and float(L["param_N"]) == 60 and float(L["param_mu"]) == 1.0
+    for i in (0, 1):
+        Xp = L[f"pred{i}_state"]; fz = L[f"pred{i}_fz"]
+        assert Xp.shape == (12, 61) and fz.shape == (4, 60)
+        assert np.abs(Xp[3:6, 1:] - (Xp[3:6, :-1] + d * Xp[9:12, :-1])).max() <= 5e-3
+        vz_model = Xp[11, :-1] + d * (fz.sum(axis=0) / 8.885 + g)
+        assert np.abs(Xp[11, 1:] - vz_model).max() <= 5e-3          # m = 8.885 (8.782 from the URDF would miss by >5e-3? no: pinned loosely)
+        # the same residual with a 10 % different mass is clearly worse -> the log does discriminate the constant
+        vz_bad = Xp[11, :-1] + d * (fz.sum(axis=0) / (8.885 * 1.1) + g)
+        assert np.abs(Xp[11, 1:] - vz_bad).max() > 2 * np.abs(Xp[11, 1:] - vz_model).max()
+
+
+def test_qp_inputs_reproduce_logged_quantities(golden):
+    """Inputs rebuilt for the golden ticks equal the logged per-tick data exactly (x0, x_des(:,0), stage-0 lever arms)."""
+    L, q = golden["ref_log"], golden["qp_inputs"]
+    for N in (10, 20, 60):
+        for j, t in enumerate(q["ticks"]):
+            assert np.array_equal(q[f"N{N}_x0"][j][:12], L["actual"][t]) and q[f"N{N}_x0"][j][12] == -9.81
+            assert np.array_equal(q[f"N{N}_xdes"][j][0][:12], L["desired"][t])
+            assert np.array_equal(q[f"N{N}_r"][j][0], L["feet_actual"][t] - L["actual"][t][3:6])
+            assert set(np.unique(q[f"N{N}_contact"][j])) <= {0, 1}
+
+
+def test_oracle_not_worse_than_logged_osqp_prediction(oracle_solve, golden):
+    """At the reference's own cost (alpha = 0, N = 60, delta = 0.01) the oracle's optimum must be at least as good
+    as the prediction OSQP logged at t = 0 and t = 80 (which is visibly unconverged)."""
+    L, q = golden["ref_log"], golden["qp_inputs"]
+    cfg = S.QPConfig(N=60, delta=0.01, alpha=0.0)
+    for i, t in ((0, 0), (1, 80)):
+        j = int(np.where(q["ticks"] == t)[0][0])
+        x0, r, c, xd, mu = _qp(golden, 60, j)
+        Xlog = np.vstack([L[f"pred{i}_state"], np.full((1, 61), -9.81)]).T          # [61,13]
+        Jlog = S.objective(Xlog, np.zeros(1), xd, cfg)
+        Jor = float(golden["qp_optima"]["N60_a0_J"][j])
+        assert Jor <= Jlog * (1 + 1e-9)
+        assert np.abs(golden["qp_optima"]["N60_a0_X"][j][:, :12] - Xlog[:, :12]).max() < 0.5   # same basin, loose
+
+
+def test_golden_optima_reproduced(oracle_solve, golden):
+    q, opt = golden["qp_inputs"], golden["qp_optima"]
+    for N in (10, 20):
+        b = {"x0": q[f"N{N}_x0"], "r": q[f"N{N}_r"], "contact": q[f"N{N}_contact"], "xdes": q[f"N{N}_xdes"],
+             "mu": np.full(len(q["ticks"]), float(q["mu"]))}
+        for alpha, tag in ((1e-2, "a1e-2"), (1e-4, "a1e-4")):
+            sol = oracle_solve(b, N=N, delta=float(q["delta"]), alpha=alpha)
+            assert np.all(sol["status"] == 1)
+            assert rel_err(sol["u"], opt[f"N{N}_{tag}_u"]).max() <= 1e-8
+            assert np.abs(sol["X"] - opt[f"N{N}_{tag}_X"]).max() <= 1e-9
+
+
+def test_alpha0_unique_quantities(oracle_solve, golden):
+    """alpha = 0 (the reference's cost): forces are not unique, objective / states / net wrench are."""
+    q, opt = golden["qp_inputs"], golden["qp_optima"]
+    N = 10
+    b = {"x0": q[f"N{N}_x0"], "r": q[f"N{N}_r"], "contact": q[f"N{N}_contact"], "xdes": q[f"N{N}_xdes"],
+         "mu": np.full(len(q["ticks"]), float(q["mu"]))}
+    sol = oracle_solve(b, N=N, delta=float(q["delta"]), alpha=0.0, rho=0.3, max_iter=20000)
+    cfg = S.QPConfig(N=N, delta=float(q["delta"]), alpha=0.0)
+    ok = sol["status"] != 3
+    assert ok.sum() >= 7
+    for i in np.where(ok)[0]:
+        J = S.objective(sol["X"][i], sol["u"][i], b["xdes"][i], cfg)
+        assert abs(J - opt["N10_a0_J"][i]) <= 1e-6 * max(1.0, abs(J))
+        assert np.abs(sol["X"][i] - opt["N10_a0_X"][i]).max() <= 1e-5
+
+
+def test_nonfinite_input_flagged(oracle_solve):
+    b = mpcqp.synth.config2(4)
+    b["x0"][2, 4] = np.nan
+    sol = oracle_solve(b)
+    assert sol["status"][2] == -1 and np.all(sol["u"][2] == 0)
+    assert np.all(sol["status"][[0, 1, 3]] == 1)
