@@ -44,16 +44,23 @@ def cpu_baseline(batch, cfg_kw, sample):
     path = os.path.join(REPO, "oracle", "libmpcqp_oracle.so")
     if not os.path.exists(path):
         return None
+    cores = len(os.sched_getaffinity(0))               # the threads OpenMP will actually get
+    os.environ["OMP_NUM_THREADS"] = str(cores)         # read by libgomp when the library is loaded below
     lib = mpcqp.Library(path)
     eng = mpcqp.Engine(lib, lib.default_config(**cfg_kw))
     sub = {k: batch[k][:sample] for k in ("x0", "r", "contact", "xdes", "mu")}
+    eng.solve_batch_host(sub["x0"][:cores], sub["r"][:cores], sub["contact"][:cores], sub["xdes"][:cores], sub["mu"][:cores], want_X=False)
+    reps, dt, st = 0, 0.0, None
     t0 = time.perf_counter()
-    out = eng.solve_batch_host(sub["x0"], sub["r"], sub["contact"], sub["xdes"], sub["mu"], want_X=False)
-    dt = time.perf_counter() - t0
-    st = out["status"]
-    return {"value": sample / dt, "unit": "QP solves/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"first {sample} QPs of the same batch, fp64 condensed OSQP-style ADMM + polish, OpenMP over the batch, "
-                      f"{dt:.1f} s wall; solved fraction {float(((st == 1) | (st == 2)).mean()):.3f}"}
+    while dt < 10.0 and reps < 64:                      # bounded: about 10 s of wall on the host cores
+        out = eng.solve_batch_host(sub["x0"], sub["r"], sub["contact"], sub["xdes"], sub["mu"], want_X=False)
+        reps += 1
+        dt = time.perf_counter() - t0
+        st = out["status"]
+    return {"value": reps * sample / dt, "unit": "QP solves/s", "cores": cores, "kind": "port",
+            "sample": f"first {sample} QPs of the same batch x {reps} passes, fp64 condensed OSQP-style ADMM + polish (same rho/sigma/"
+                      f"relax/iteration cap as the GPU run), OpenMP over the batch, {dt:.1f} s wall; solved fraction "
+                      f"{float(((st == 1) | (st == 2)).mean()):.3f}"}
 
 
 def main():
