@@ -44,7 +44,14 @@ def cpu_baseline(batch, cfg_kw, sample):
     path = os.path.join(REPO, "oracle", "libmpcqp_oracle.so")
     if not os.path.exists(path):
         return None
-    cores = len(os.sched_getaffinity(0))               # the threads OpenMP will actually get
+    cores = len(os.sched_getaffinity(0))               # the threads OpenMP will actually get ...
+    try:                                               # ... capped by the container's CPU quota (cgroup v2), if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, 64)
     os.environ["OMP_NUM_THREADS"] = str(cores)         # read by libgomp when the library is loaded below
     lib = mpcqp.Library(path)
     eng = mpcqp.Engine(lib, lib.default_config(**cfg_kw))
@@ -147,7 +154,9 @@ def main():
                        "solved_fraction": solved, "admm_iters_mean": k_mean, "polish_steps_mean": float((iters // 1000).mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                         "kernel": "mpcqp_solve_kernel<float,double,float,10>", "kernel_ms": kernel_ms, "kernel_ms_last_launch": last_ms,
+                         "kernel": "one solve_batch = mpcqp_fast_admm<float> + mpcqp_fast_polish<double,float>, x rounds "
+                                   "(rocprofv3 kernel stats: sum of TotalDurationNs of both / steps)",
+                         "kernel_ms": kernel_ms, "kernel_ms_last_launch": last_ms,
                          "algorithmic_flops_per_qp": flops,
                          "hbm": {"achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS,
                                  "algorithmic_bytes_per_qp": algorithmic_bytes(N), "note": "non-binding roof (SURVEY 8d)"}},

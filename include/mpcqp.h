@@ -59,6 +59,7 @@ extern "C" {
 /* flags */
 #define MPCQP_FLAG_POLISH 1u     /* active-set polish after ADMM (OSQP's `polish`; the reference leaves it off) */
 #define MPCQP_FLAG_WARM_START 2u /* keep (u, z, y) per batch slot between calls (src/mpc.py:270-271 is primal-only) */
+#define MPCQP_FLAG_GENERAL_KERNEL 4u /* product library: use the single-launch general kernel even where the fast path applies */
 
 /*
  * Problem + solver configuration.  POD, versioned by its leading `size` field (set to sizeof(MpcQpConfig)).

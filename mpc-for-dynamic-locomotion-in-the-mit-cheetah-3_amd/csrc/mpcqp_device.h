@@ -1,0 +1,205 @@
+// mpcqp_device.h -- device-side helpers shared by the general and the fast-path kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/mpcqp.h"
+
+// Occupancy target for the N = 10 kernels (waves per SIMD -> VGPR cap 128 / 168 / 256); tuned on hardware.
+#ifndef MPCQP_WPE
+#define MPCQP_WPE 4
+#endif
+
+namespace {
+
+// Diagnostic build only (-DMPCQP_STAMPS -> libmpcqp_stamps.so): per-phase shader-cycle sums over all workgroups.
+// Never compiled into libmpcqp.so; the values leave through their own buffer and feed no output.
+#ifdef MPCQP_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define STAMP_INIT unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_t1;
+#define STAMP(i)                                                       \
+  do {                                                                 \
+    st_t1 = __builtin_amdgcn_s_memtime();                              \
+    if (threadIdx.x == 0) {                                            \
+      atomicAdd(&g_stamps[i], st_t1 - st_t0);                          \
+      atomicAdd(&g_stamps[16 + i], 1ull);                              \
+    }                                                                  \
+    st_t0 = st_t1;                                                     \
+  } while (0)
+#else
+#define STAMP_INIT
+#define STAMP(i)
+#endif
+
+struct DevCfg {
+  double delta, inv_m, Ib[3], w[12], sw[12], alpha, fmin, fmax, rho, sigma, relax, eps_abs, eps_rel, theta;
+  int max_iter, check_every, polish_max;
+  unsigned flags;
+};
+
+// Problem constants staged in LDS in the vector precision (keeps ~100 scalar registers free).
+template <typename TV>
+struct CfgS {
+  TV delta, theta, alpha, inv_m, fmin, fmax;
+  TV Ib[3], w[12], sw[12];
+};
+
+// Sum over the 8 lanes of a leg group with DPP lane moves (no LDS crossbar): quad butterfly, then half-row mirror.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ T group8_sum(T v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror: lane i <-> 7 - i inside each group of 8
+  return v;
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+// Workgroup-wide max of Q floats; every thread gets the result.  NaN-propagating via the isnan flag in slot Q-1
+// is the caller's business.  Two barriers.
+template <int Q, int NW>
+__device__ __forceinline__ void block_max(float (&v)[Q], float* red, int tid) {
+#pragma unroll
+  for (int q = 0; q < Q; ++q) v[q] = wave_max(v[q]);
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) red[(tid >> 6) * 4 + q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    float m = red[q];
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w * 4 + q]);
+    v[q] = m;
+  }
+  __syncthreads();
+}
+
+// Gradient of the reference cost (src/mpc.py:121-134, + alpha |u|^2) at s.uv, by rollout + adjoint.
+// Needs s.uv visible (barrier before the call).  Leaves s.gv, s.Xs (states), s.es (weighted errors); ends
+// with a barrier.  Closed forms: for Euler (theta = 0) / ZOH (theta = 1/2)
+//   omega_k = omega_0 + d sum_{j<k} tau_j                      v_k = v_0 + d sum_{j<k} a_j + k d g e_z
+//   Theta_k = Theta_0 + k d Rz omega_0 + d^2 sum_{j<k} (k-1-j+theta) Rz tau_j
+//   p_k     = p_0 + k d v_0 + d^2 sum_{j<k} (k-1-j+theta) a_j + d^2 g (k(k-1)/2 + theta k) e_z
+// with tau_j = sum_i tt_i u_i, a_j = sum_i cm_i u_i e_axis(i) over the variables of stage j
+// (src/mpc.py:86-117 restated; tt_i = I_hat_inv (r x e_axis), src/mpc.py:78,98-107).
+template <typename SM, typename TV, int N>
+__device__ __forceinline__ void struct_grad(SM& s, int tid) {
+  constexpr int n = 12 * N;
+  const TV d = s.cf.delta, th = s.cf.theta;
+  if (tid < N * 9) {
+    const int j = tid / 9, q = tid % 9;
+    TV acc = 0;
+    if (q < 3) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) acc += s.tt[(12 * j + i) * 3 + q] * s.uv[12 * j + i];
+    } else if (q < 6) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) acc += s.ttr[(12 * j + i) * 3 + (q - 3)] * s.uv[12 * j + i];
+    } else {
+#pragma unroll
+      for (int l = 0; l < 4; ++l) acc += s.cm[12 * j + 3 * l + (q - 6)] * s.uv[12 * j + 3 * l + (q - 6)];
+    }
+    s.wr[tid] = acc;
+  }
+  __syncthreads();
+  if (tid < N * 12) {
+    const int k = tid / 12 + 1, c = tid % 12, dd = c % 3;
+    const TV g = s.x0[12];
+    TV val;
+    if (c < 3) {
+      TV acc = 0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc += (j < k) ? ((TV)(k - 1 - j) + th) * s.wr[j * 9 + 3 + dd] : (TV)0;
+      val = s.x0[dd] + (TV)k * d * s.rzw0[dd] + d * d * acc;
+    } else if (c < 6) {
+      TV acc = 0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc += (j < k) ? ((TV)(k - 1 - j) + th) * s.wr[j * 9 + 6 + dd] : (TV)0;
+      val = s.x0[3 + dd] + (TV)k * d * s.x0[9 + dd] + d * d * acc;
+      if (dd == 2) val += d * d * g * ((TV)(k * (k - 1)) * (TV)0.5 + th * (TV)k);
+    } else if (c < 9) {
+      TV acc = 0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc += (j < k) ? s.wr[j * 9 + dd] : (TV)0;
+      val = s.x0[6 + dd] + d * acc;
+    } else {
+      TV acc = 0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc += (j < k) ? s.wr[j * 9 + 6 + dd] : (TV)0;
+      val = s.x0[9 + dd] + d * acc;
+      if (dd == 2) val += (TV)k * d * g;
+    }
+    s.Xs[k * 12 + c] = val;
+    s.es[k * 12 + c] = s.cf.w[c] * (val - s.xd[k * 13 + c]);
+  }
+  __syncthreads();
+  if (tid < N * 9) {
+    const int j = tid / 9, q = tid % 9, dd = q % 3;
+    TV out;
+    if (q < 3) {
+      TV acc = 0;
+#pragma unroll
+      for (int k = 1; k <= N; ++k) acc += (k > j) ? s.es[k * 12 + 6 + dd] : (TV)0;
+      out = (TV)2 * d * acc;
+    } else if (q < 6) {
+      TV acc = 0;
+#pragma unroll
+      for (int k = 1; k <= N; ++k) acc += (k > j) ? ((TV)(k - 1 - j) + th) * s.es[k * 12 + dd] : (TV)0;
+      out = (TV)2 * d * d * acc;
+    } else {
+      TV a1 = 0, a2 = 0;
+#pragma unroll
+      for (int k = 1; k <= N; ++k) {
+        a1 += (k > j) ? s.es[k * 12 + 9 + dd] : (TV)0;
+        a2 += (k > j) ? ((TV)(k - 1 - j) + th) * s.es[k * 12 + 3 + dd] : (TV)0;
+      }
+      out = (TV)2 * d * a1 + (TV)2 * d * d * a2;
+    }
+    s.adj[tid] = out;
+  }
+  __syncthreads();
+  if (tid < n) {
+    const int j = tid / 12, a = tid % 3;
+    TV gsum = (TV)2 * s.cf.alpha * s.uv[tid];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) gsum += s.tt[tid * 3 + q] * s.adj[j * 9 + q] + s.ttr[tid * 3 + q] * s.adj[j * 9 + 3 + q];
+    gsum += s.cm[tid] * s.adj[j * 9 + 6 + a];
+    s.gv[tid] = gsum;
+  }
+  __syncthreads();
+}
+
+// Weighted 12-vector [P(6) | Q(6)] of force variable i (axis a): H_ii' = 2 (c1 P.P' + c0 Q.Q').
+template <typename SM, typename TV>
+__device__ __forceinline__ void var_pq(const SM& s, int i, int a, TV (&o)[12]) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    o[q] = s.cf.sw[q] * s.ttr[i * 3 + q];
+    o[3 + q] = (q == a) ? s.cf.sw[3 + q] * s.cm[i] : (TV)0;
+    o[6 + q] = s.cf.sw[6 + q] * s.tt[i * 3 + q];
+    o[9 + q] = (q == a) ? s.cf.sw[9 + q] * s.cm[i] : (TV)0;
+  }
+}
+
+}  // namespace

@@ -1,0 +1,613 @@
+// mpcqp_fast.h -- fast path for the benchmarked configuration: horizon 10, ADMM + active-set polish, fp32 matrix
+// tiles with fp64 (MIXED) or fp32 (F32) structured residuals.
+//
+// Two kernels per round, chained through a small HBM workspace, instead of one monolithic kernel:
+//   mpcqp_fast_admm    setup -> M = H + diag -> in-register sweep -> K ADMM iterations        (pure fp32)
+//   mpcqp_fast_polish  setup -> active set -> reduced matrix -> sweep -> refined solve -> KKT  (fp32 tiles + TV)
+// Splitting keeps each kernel's register budget separate (no scratch), so several workgroups share a CU; a QP that
+// is solved leaves the pipeline (later rounds exit at the first instruction), the rest get K more iterations with an
+// OSQP-adapted rho and another polish.
+//
+// Geometry (n = 120 force variables, 40 leg-stages): thread (g, c) of a 160-thread workgroup (192 launched: the
+// last 32 mirror group 19 so every wave is full) owns rows 6g..6g+5 (two leg-stages) and columns 15c..15c+14 as a
+// 6 x 16 register tile (column 15 is padding and stays zero, so packed fp32 FMAs pair up).  LDS vectors are stored in
+// 8 chunks of 15 with a chunk stride of 20 floats: the 128-bit reads of the 8 lanes of a group then fall on disjoint
+// banks (a stride of 16 puts them on two: 4-way conflicts, 60 % of all LDS cycles in the first version).
+#pragma once
+#include "mpcqp_device.h"
+
+namespace {
+
+struct FG {
+  static constexpr int N = 10, n = 120, NL = 40;
+  static constexpr int RT = 6, CT = 8, CW = 15, CWP = 16;
+  static constexpr int S = 20;             // chunk stride of LDS vectors (floats)
+  static constexpr int VP = CT * S;
+  static constexpr int NG = n / RT;        // 20 row groups
+  static constexpr int NT = 192;           // threads launched (160 + 32 mirrors)
+  static constexpr int NW = 3;
+  static constexpr int WS = NL * 13 + 4;   // workspace floats per QP: (u3, z5, y5) per leg-stage + rho + spare
+};
+
+template <typename TV>
+struct SmemF {
+  CfgS<TV> cf;
+  TV x0[13];
+  TV mu, cy, sy;
+  TV rzw0[3];
+  TV xd[11 * 13];
+  TV rr[120];
+  TV tt[360], ttr[360];
+  TV cm[120];
+  TV wr[90], Xs[132], es[132], adj[90];
+  TV uv[120], gv[120], gl[120];
+  TV pu[120], py[200];
+  float ua[120], za[200], ya[200];          // last ADMM iterate (polish kernel: fallback answer + rho adaptation)
+  float c0[100], c1[100];
+  alignas(16) float pq[120 * 12];
+  float dg[120];
+  alignas(16) float vbuf[2 * FG::VP];
+  alignas(16) float rhs[2 * FG::VP];
+  float red[FG::NW * 4];
+  uint8_t ct[40];
+  uint8_t em[40];
+};
+
+__device__ __forceinline__ int fpidx(int i) { return (i / FG::CW) * FG::S + i % FG::CW; }
+
+// Load the operator tuple, build the per-variable response vectors and the linear term g.  Returns the uniform
+// "non-finite input" flag.  Ends with a barrier.
+template <typename TV, typename TIO>
+__device__ __forceinline__ int fast_setup(SmemF<TV>& s, const DevCfg& cfg, const double* __restrict__ ctab,
+                                          const TIO* __restrict__ x0g, const TIO* __restrict__ rg,
+                                          const uint8_t* __restrict__ cg, const TIO* __restrict__ xdg,
+                                          const TIO* __restrict__ mug, size_t b, int tid) {
+  constexpr int N = FG::N, n = FG::n, NT = FG::NT;
+  int bad = 0;
+  for (int i = tid; i < 13; i += NT) { const TV v = (TV)x0g[b * 13 + i]; s.x0[i] = v; bad |= !isfinite(v); }
+  for (int i = tid; i < (N + 1) * 13; i += NT) { const TV v = (TV)xdg[b * (N + 1) * 13 + i]; s.xd[i] = v; bad |= !isfinite(v); }
+  for (int i = tid; i < N * 12; i += NT) { const TV v = (TV)rg[b * N * 12 + i]; s.rr[i] = v; bad |= !isfinite(v); }
+  for (int i = tid; i < N * 4; i += NT) s.ct[i] = cg[b * N * 4 + i] ? 1 : 0;
+  for (int i = tid; i < N * N; i += NT) { s.c0[i] = (float)ctab[i]; s.c1[i] = (float)ctab[N * N + i]; }
+  for (int i = tid; i < 2 * FG::VP; i += NT) { s.vbuf[i] = 0.f; s.rhs[i] = 0.f; }   // pad slots must stay finite
+  if (tid == 0) {
+    const TV m = (TV)mug[b];
+    s.mu = m;
+    bad |= !isfinite(m);
+    s.cf.delta = (TV)cfg.delta; s.cf.theta = (TV)cfg.theta; s.cf.alpha = (TV)cfg.alpha; s.cf.inv_m = (TV)cfg.inv_m;
+    s.cf.fmin = (TV)cfg.fmin; s.cf.fmax = (TV)cfg.fmax;
+  }
+  if (tid >= 64 && tid < 76) { s.cf.w[tid - 64] = (TV)cfg.w[tid - 64]; s.cf.sw[tid - 64] = (TV)cfg.sw[tid - 64]; }
+  if (tid >= 128 && tid < 131) s.cf.Ib[tid - 128] = (TV)cfg.Ib[tid - 128];
+  bad = __syncthreads_or(bad);
+  if (bad) return 1;
+  if (tid == 0) {
+    const TV yaw = s.x0[2];  // src/mpc.py:64
+    const TV c = cos(yaw), sn = sin(yaw);
+    s.cy = c; s.sy = sn;
+    s.rzw0[0] = c * s.x0[6] - sn * s.x0[7];
+    s.rzw0[1] = sn * s.x0[6] + c * s.x0[7];
+    s.rzw0[2] = s.x0[8];
+  }
+  __syncthreads();
+  if (tid < n) {  // src/mpc.py:71-78, 98-107; compute_skew column a = r x e_a (src/utils.py:43-56)
+    const int i = tid, j = i / 12, l = (i % 12) / 3, a = i % 3;
+    const bool st = s.ct[j * 4 + l] != 0;
+    const TV rx = s.rr[(j * 4 + l) * 3 + 0], ry = s.rr[(j * 4 + l) * 3 + 1], rz = s.rr[(j * 4 + l) * 3 + 2];
+    TV cx, cyv, cz;
+    if (a == 0) { cx = 0; cyv = rz; cz = -ry; }
+    else if (a == 1) { cx = -rz; cyv = 0; cz = rx; }
+    else { cx = ry; cyv = -rx; cz = 0; }
+    const TV c = s.cy, sn = s.sy;
+    TV bx = (c * cx + sn * cyv) * s.cf.Ib[0], by = (-sn * cx + c * cyv) * s.cf.Ib[1], bz = cz * s.cf.Ib[2];
+    TV tx = c * bx - sn * by, ty = sn * bx + c * by, tz = bz;
+    if (!st) { tx = ty = tz = 0; }
+    s.tt[i * 3 + 0] = tx; s.tt[i * 3 + 1] = ty; s.tt[i * 3 + 2] = tz;
+    s.ttr[i * 3 + 0] = c * tx - sn * ty; s.ttr[i * 3 + 1] = sn * tx + c * ty; s.ttr[i * 3 + 2] = tz;
+    s.cm[i] = st ? s.cf.inv_m : (TV)0;
+    s.uv[i] = 0;
+  }
+  __syncthreads();
+  struct_grad<SmemF<TV>, TV, N>(s, tid);   // gradient at u = 0 = linear term g
+  if (tid < n) s.gl[tid] = s.gv[tid];
+  __syncthreads();
+  return 0;
+}
+
+// Register tile M[6g..6g+5][15c..15c+14] = 2 (c1 P.P' + c0 Q.Q') + diag, from s.pq / s.dg (two passes of three rows).
+template <typename TV>
+__device__ __forceinline__ void fast_build(float (&tile)[6][16], const SmemF<TV>& s, int grp, int cc) {
+  constexpr int N = FG::N;
+  const int col0 = cc * FG::CW;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r0 = 6 * grp + 3 * h, stage = r0 / 12;
+    float Pr[3][12];
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3) {
+      const float4* pp = reinterpret_cast<const float4*>(s.pq + (r0 + r3) * 12);
+#pragma unroll
+      for (int q4 = 0; q4 < 3; ++q4) { const float4 v = pp[q4]; Pr[r3][4 * q4] = v.x; Pr[r3][4 * q4 + 1] = v.y; Pr[r3][4 * q4 + 2] = v.z; Pr[r3][4 * q4 + 3] = v.w; }
+    }
+#pragma unroll
+    for (int c = 0; c < FG::CW; ++c) {
+      asm volatile("" ::: "memory");  // keep the column loads of different columns from piling up in registers
+      const int ic = col0 + c, jc = ic / 12;
+      const float k1 = 2.f * s.c1[stage * N + jc], k0 = 2.f * s.c0[stage * N + jc];
+      float pc[12];
+      const float4* pp = reinterpret_cast<const float4*>(s.pq + ic * 12);
+#pragma unroll
+      for (int q4 = 0; q4 < 3; ++q4) { const float4 v = pp[q4]; pc[4 * q4] = v.x; pc[4 * q4 + 1] = v.y; pc[4 * q4 + 2] = v.z; pc[4 * q4 + 3] = v.w; }
+#pragma unroll
+      for (int r3 = 0; r3 < 3; ++r3) {
+        float dp = 0.f, dq = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { dp += Pr[r3][q] * pc[q]; dq += Pr[r3][6 + q] * pc[6 + q]; }
+        float v = k1 * dp + k0 * dq;
+        if (ic == r0 + r3) v += s.dg[ic];
+        tile[3 * h + r3][c] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) tile[r][15] = 0.f;
+}
+
+// In-register symmetric sweep over the enabled variables: tile <- -M^{-1} (Gauss-Jordan without pivoting, SPD).
+// One LDS broadcast of the pivot row and one barrier per pivot; disabled variables (identity rows) are skipped.
+template <typename TV>
+__device__ __forceinline__ void fast_sweep(float (&tile)[6][16], SmemF<TV>& s, int grp, int cc, int rbA, int rbB) {
+  constexpr int S = FG::S, VP = FG::VP;
+  int step = 0;
+  for (int kc2 = 0; kc2 < 4; ++kc2) {
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int kc = 2 * kc2 + par;
+      int em = 0;
+#pragma unroll
+      for (int c = 0; c < FG::CW; ++c) {
+        const int rr = (c + 3 * par) % 6;        // row inside the owner's tile (compile-time after unrolling)
+        const int k = FG::CW * kc + c;           // pivot index
+        if (c % 3 == 0) em = s.em[k / 3];        // uniform: enable mask of the pivot's leg-stage
+        if (!((em >> (c % 3)) & 1)) continue;
+        const int og = k / 6;
+        float* vb = s.vbuf + (step & 1) * VP;
+        if (grp == og) {
+          float4* w4 = reinterpret_cast<float4*>(vb + cc * S);
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) w4[q4] = make_float4(tile[rr][4 * q4], tile[rr][4 * q4 + 1], tile[rr][4 * q4 + 2], tile[rr][4 * q4 + 3]);
+        }
+        __syncthreads();
+        const float p = __builtin_amdgcn_rcpf(vb[kc * S + c]);
+        float vr[6], vc[16];
+#pragma unroll
+        for (int r3 = 0; r3 < 3; ++r3) { vr[r3] = vb[rbA + r3] * p; vr[3 + r3] = vb[rbB + r3] * p; }
+        {
+          const float4* r4 = reinterpret_cast<const float4*>(vb + cc * S);
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) { const float4 v = r4[q4]; vc[4 * q4] = v.x; vc[4 * q4 + 1] = v.y; vc[4 * q4 + 2] = v.z; vc[4 * q4 + 3] = v.w; }
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c2 = 0; c2 < 16; ++c2) tile[r][c2] -= vr[r] * vc[c2];
+        if (grp == og) {
+#pragma unroll
+          for (int c2 = 0; c2 < 16; ++c2) tile[rr][c2] = vc[c2] * p;
+        }
+        if (cc == kc) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) tile[r][c] = vr[r];
+          if (grp == og) tile[rr][c] = -p;
+        }
+        ++step;
+      }
+    }
+  }
+}
+
+// out[r] = -(tile row r) . x, summed over the 8 lanes of the group (x in the padded LDS layout).
+__device__ __forceinline__ void fast_matvec(const float (&tile)[6][16], const float* __restrict__ x, int cc, float (&out)[6]) {
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float4* r4 = reinterpret_cast<const float4*>(x + cc * FG::S);
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const float4 v = r4[q4];
+    const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc[r] += tile[r][4 * q4 + e] * xv[e];
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) out[r] = -group8_sum(acc[r]);
+}
+
+// Writes the 12-vectors / diagonal / enable mask of one leg-stage's three variables (lanes a = 0..2 of the leg's
+// four lanes; lane 3 writes the mask).  mode 0: ADMM matrix H + sigma I + rho G'G; mode 1: reduced polish matrix.
+template <typename TV>
+__device__ __forceinline__ void fast_describe(SmemF<TV>& s, int myleg, int a, bool stance, TV muv, int mode, float rho,
+                                              float sigma, int zs, int xs, int ys) {
+  const int row0 = 3 * myleg;
+  const bool ez = stance && (mode == 0 || zs == 0), ex = stance && (mode == 0 || xs == 0), ey = stance && (mode == 0 || ys == 0);
+  if (a < 3) {
+    const bool en = a == 0 ? ex : (a == 1 ? ey : ez);
+    TV pv[12];
+    var_pq<SmemF<TV>, TV>(s, row0 + a, a, pv);
+    const TV a2 = (TV)2 * s.cf.alpha;
+    TV dgv;
+    if (mode == 0) {
+      dgv = stance ? a2 + (TV)sigma + (TV)rho * (a == 2 ? (TV)1 + (TV)4 * muv * muv : (TV)2) : (TV)1;
+    } else {
+      if (a == 2 && ez) {  // tied tangential forces ride on the fz slot
+        TV px[12], py_[12];
+        var_pq<SmemF<TV>, TV>(s, row0 + 0, 0, px);
+        var_pq<SmemF<TV>, TV>(s, row0 + 1, 1, py_);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) pv[q] += (TV)xs * muv * px[q] + (TV)ys * muv * py_[q];
+      }
+      dgv = !en ? (TV)1 : (a == 2 ? a2 * ((TV)1 + muv * muv * (TV)((xs != 0) + (ys != 0))) : a2);
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) s.pq[(row0 + a) * 12 + q] = en ? (float)pv[q] : 0.f;
+    s.dg[row0 + a] = (float)dgv;
+  } else {
+    s.em[myleg] = (uint8_t)((ex ? 1 : 0) | (ey ? 2 : 0) | (ez ? 4 : 0));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------ kernel A
+template <typename TIO>
+__global__ void __launch_bounds__(FG::NT)
+mpcqp_fast_admm(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const TIO* __restrict__ x0g,
+                const TIO* __restrict__ rg, const uint8_t* __restrict__ cg, const TIO* __restrict__ xdg,
+                const TIO* __restrict__ mug, TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __restrict__ statusg,
+                int* __restrict__ itersg, float* __restrict__ resg, float* __restrict__ ws, int first) {
+  constexpr int N = FG::N, n = FG::n, NT = FG::NT, S = FG::S, VP = FG::VP;
+  const size_t b = blockIdx.x;
+  if (!first && statusg[b] != MPCQP_STATUS_UNSOLVED) return;   // solved (or flagged) in an earlier round
+  __shared__ SmemF<float> s;
+  const DevCfg& cfg = *cfgp;
+  const int tid = threadIdx.x;
+  const int grp = min(tid / 8, FG::NG - 1);   // threads 160..191 mirror group 19 (full waves, identical writes)
+  const int cc = tid % 8;
+  const bool second = cc >= 4;                // lanes 0-3 look after leg-stage 2g, lanes 4-7 after 2g+1
+  const int myleg = 2 * grp + (second ? 1 : 0);
+  const int rbA = fpidx(6 * grp), rbB = fpidx(6 * grp + 3);
+  const int rbM = second ? rbB : rbA;
+  STAMP_INIT
+  if (fast_setup<float, TIO>(s, cfg, ctab, x0g, rg, cg, xdg, mug, b, tid)) {
+    for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
+    if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (N + 1) * 13 + i] = (TIO)0;
+    if (tid == 0) {
+      statusg[b] = MPCQP_STATUS_NONFINITE;
+      itersg[b] = 0;
+      if (resg) { resg[2 * b] = 0.f; resg[2 * b + 1] = 0.f; }
+    }
+    return;
+  }
+  float* wq = ws + b * FG::WS;
+  const bool stance = s.ct[myleg] != 0;
+  const float mu = s.mu;
+  const float rho = first ? (float)cfg.rho : wq[FG::NL * 13];
+  const float sigma = (float)cfg.sigma, relax = (float)cfg.relax;
+  STAMP(0);
+  fast_describe<float>(s, myleg, cc & 3, stance, mu, 0, rho, sigma, 0, 0, 0);
+  __syncthreads();
+  STAMP(1);
+  float tile[6][16];
+  fast_build<float>(tile, s, grp, cc);
+  STAMP(2);
+  fast_sweep<float>(tile, s, grp, cc, rbA, rbB);
+  STAMP(3);
+
+  // ADMM (OSQP algorithm 1) on the rows  fz | fx - mu fz | fx + mu fz | fy - mu fz | fy + mu fz  of my leg-stage
+  const float BIG = 1e30f;
+  const float lo0 = stance ? (float)cfg.fmin : 0.f, hi0 = stance ? (float)cfg.fmax : 0.f;   // src/mpc.py:151-157
+  const float hiP = stance ? BIG : 0.f, loM = stance ? -BIG : 0.f;                         // src/mpc.py:159-173
+  float g3[3], u3[3], z5[5], y5[5];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { g3[c] = s.gl[3 * myleg + c]; u3[c] = first ? 0.f : wq[myleg * 13 + c]; }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { z5[i] = first ? 0.f : wq[myleg * 13 + 3 + i]; y5[i] = first ? 0.f : wq[myleg * 13 + 8 + i]; }
+  const float inv_rho = 1.f / rho;
+  auto write_rhs = [&](int bsel) {
+    float v[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] = rho * z5[i] - y5[i];
+    if ((cc & 3) == 0) {
+      float* rb = s.rhs + bsel * VP;
+      rb[rbM + 0] = sigma * u3[0] - g3[0] + v[1] + v[2];
+      rb[rbM + 1] = sigma * u3[1] - g3[1] + v[3] + v[4];
+      rb[rbM + 2] = sigma * u3[2] - g3[2] + v[0] + mu * (-v[1] + v[2] - v[3] + v[4]);
+    }
+  };
+  write_rhs(0);
+  __syncthreads();
+  const int K = cfg.check_every;
+  int buf = 0;
+  for (int it = 0; it < K; ++it) {
+    float sum[6];
+    fast_matvec(tile, s.rhs + buf * VP, cc, sum);
+    const float ut[3] = {second ? sum[3] : sum[0], second ? sum[4] : sum[1], second ? sum[5] : sum[2]};
+    const float zt[5] = {ut[2], ut[0] - mu * ut[2], ut[0] + mu * ut[2], ut[1] - mu * ut[2], ut[1] + mu * ut[2]};
+    const float lo[5] = {lo0, loM, 0.f, loM, 0.f}, hi[5] = {hi0, 0.f, hiP, 0.f, hiP};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u3[c] = relax * ut[c] + (1.f - relax) * u3[c];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const float zr = relax * zt[i] + (1.f - relax) * z5[i];
+      float zn = zr + y5[i] * inv_rho;
+      zn = zn < lo[i] ? lo[i] : (zn > hi[i] ? hi[i] : zn);
+      y5[i] += rho * (zr - zn);
+      z5[i] = zn;
+    }
+    buf ^= 1;
+    write_rhs(buf);
+    __syncthreads();
+  }
+  STAMP(4);
+  if ((cc & 3) == 0 && tid < FG::NG * 8) {   // park (u, z, y) of my leg-stage for the polish kernel / the next round
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wq[myleg * 13 + c] = u3[c];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { wq[myleg * 13 + 3 + i] = z5[i]; wq[myleg * 13 + 8 + i] = y5[i]; }
+  }
+  if (tid == 0) {
+    wq[FG::NL * 13] = rho;
+    if (first) { statusg[b] = MPCQP_STATUS_UNSOLVED; itersg[b] = K; }
+    else itersg[b] += K;
+  }
+  STAMP(5);
+}
+
+// ------------------------------------------------------------------------------------------------------ kernel B
+template <typename TV, typename TIO>
+__global__ void __launch_bounds__(FG::NT)
+mpcqp_fast_polish(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const TIO* __restrict__ x0g,
+                  const TIO* __restrict__ rg, const uint8_t* __restrict__ cg, const TIO* __restrict__ xdg,
+                  const TIO* __restrict__ mug, TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __restrict__ statusg,
+                  int* __restrict__ itersg, float* __restrict__ resg, float* __restrict__ ws, int last) {
+  constexpr int N = FG::N, n = FG::n, NT = FG::NT, NW = FG::NW;
+  const size_t b = blockIdx.x;
+  if (statusg[b] != MPCQP_STATUS_UNSOLVED) return;
+  __shared__ SmemF<TV> s;
+  const DevCfg& cfg = *cfgp;
+  const int tid = threadIdx.x;
+  const int grp = min(tid / 8, FG::NG - 1);
+  const int cc = tid % 8;
+  const bool second = cc >= 4;
+  const int myleg = 2 * grp + (second ? 1 : 0);
+  const int row0 = 3 * myleg;
+  const int rbA = fpidx(6 * grp), rbB = fpidx(6 * grp + 3);
+  const int rbM = second ? rbB : rbA;
+  STAMP_INIT
+  float* wq = ws + b * FG::WS;
+  for (int i = tid; i < FG::NL; i += NT) {   // last ADMM iterate -> LDS
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float v = wq[i * 13 + c]; s.ua[3 * i + c] = v; s.pu[3 * i + c] = (TV)v; }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { s.za[5 * i + k] = wq[i * 13 + 3 + k]; const float y = wq[i * 13 + 8 + k]; s.ya[5 * i + k] = y; s.py[5 * i + k] = (TV)y; }
+  }
+  (void)fast_setup<TV, TIO>(s, cfg, ctab, x0g, rg, cg, xdg, mug, b, tid);   // inputs were screened by the ADMM kernel
+  const bool stance = s.ct[myleg] != 0;
+  const TV muv = s.mu;
+  const TV fminv = s.cf.fmin, fmaxv = s.cf.fmax;
+  float gmaxf;
+  {
+    float q[1] = {fmaxf(fmaxf(fabsf((float)s.gl[row0]), fabsf((float)s.gl[row0 + 1])), fabsf((float)s.gl[row0 + 2]))};
+    block_max<1, NW>(q, s.red, tid);
+    gmaxf = q[0];
+  }
+  const float tol_stat = (sizeof(TV) == 8) ? (1e-6f + 1e-9f * gmaxf) : (3e-7f * fmaxf(gmaxf, 1.f));
+  const float acc_stat = (sizeof(TV) == 8) ? (1e-5f + 1e-8f * gmaxf) : (1e-5f * fmaxf(gmaxf, 1.f));
+  const float ftol = (sizeof(TV) == 8) ? 1e-7f : 2e-5f;
+  // dual-sign slack must stay well below alpha-curvature * force tolerance (a wrongly active row with multiplier -e
+  // moves the forces by ~e / (2 alpha))
+  const float dtol = (sizeof(TV) == 8) ? (1e-5f + 1e-9f * gmaxf) : (2e-5f * fmaxf(1.f, gmaxf));
+  const int polish_max = cfg.polish_max;
+  int psteps = 0;
+  bool ok = false;
+  float stat = INFINITY, viol[3] = {0.f, 0.f, 0.f};
+  STAMP(0);
+  float tile[6][16];
+
+  for (int ps = 0; ps < polish_max; ++ps) {
+    // primal-dual active-set rule on (pu, py): rows 0 fz | 1 fx - mu fz <= 0 | 2 fx + mu fz >= 0 | 3,4 same for fy
+    int zs = 0, xs = 0, ys = 0;
+    if (stance) {
+      const TV u0 = s.pu[row0], u1 = s.pu[row0 + 1], u2 = s.pu[row0 + 2];
+      const TV y0 = s.py[myleg * 5], y1 = s.py[myleg * 5 + 1], y2 = s.py[myleg * 5 + 2], y3 = s.py[myleg * 5 + 3], y4 = s.py[myleg * 5 + 4];
+      const TV g1 = u0 - muv * u2, g2 = u0 + muv * u2, g3_ = u1 - muv * u2, g4 = u1 + muv * u2;
+      if (y0 + (u2 - fmaxv) > 0) zs = 1;
+      else if (y0 + (u2 - fminv) < 0) zs = -1;
+      const bool hx = y1 + g1 > 0, lx = y2 + g2 < 0;
+      if (hx && lx) xs = (g1 > -g2) ? 1 : -1; else if (hx) xs = 1; else if (lx) xs = -1;
+      const bool hy = y3 + g3_ > 0, ly = y4 + g4 < 0;
+      if (hy && ly) ys = (g3_ > -g4) ? 1 : -1; else if (hy) ys = 1; else if (ly) ys = -1;
+    }
+    const bool ez = stance && zs == 0, ex = stance && xs == 0, ey = stance && ys == 0;
+    TV up3[3] = {0, 0, 0};
+    if (stance && zs != 0) {
+      const TV F = zs > 0 ? fmaxv : fminv;
+      up3[2] = F;
+      if (xs) up3[0] = (TV)xs * muv * F;
+      if (ys) up3[1] = (TV)ys * muv * F;
+    }
+    TV v3[3] = {ex ? s.pu[row0] : (TV)0, ey ? s.pu[row0 + 1] : (TV)0, ez ? s.pu[row0 + 2] : (TV)0};
+    __syncthreads();   // everyone has read pu / py of this round before pq / em are rewritten
+    fast_describe<TV>(s, myleg, cc & 3, stance, muv, 1, 0.f, 0.f, zs, xs, ys);
+    __syncthreads();
+    STAMP(1);
+    fast_build<TV>(tile, s, grp, cc);
+    STAMP(2);
+    fast_sweep<TV>(tile, s, grp, cc, rbA, rbB);
+    STAMP(3);
+
+    TV uc[3];
+    auto expand = [&]() {
+      uc[0] = up3[0]; uc[1] = up3[1]; uc[2] = up3[2];
+      if (ez) {
+        uc[2] = v3[2];
+        if (xs) uc[0] = (TV)xs * muv * v3[2];
+        if (ys) uc[1] = (TV)ys * muv * v3[2];
+      }
+      if (ex) uc[0] = v3[0];
+      if (ey) uc[1] = v3[1];
+    };
+    expand();
+    float prev_stat = INFINITY;
+    stat = INFINITY;
+    TV yn[5];
+    ok = false;
+    // stage 0: two refinement rounds, then a loose KKT screen; only a plausible candidate is refined to the tight
+    // tolerance (stage 1) and checked for real.  Wrong active sets are dropped early.
+    for (int stg = 0; stg < 2; ++stg) {
+      const float tol = stg == 0 ? fmaxf(tol_stat, 1e-3f * fmaxf(gmaxf, 1.f)) : tol_stat;
+      const int max_rf = stg == 0 ? 2 : 10;
+      TV gr[3] = {0, 0, 0};
+      for (int rf = 0;; ++rf) {
+        if ((cc & 3) == 0) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) s.uv[row0 + c] = uc[c];
+        }
+        __syncthreads();
+        struct_grad<SmemF<TV>, TV, N>(s, tid);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gr[c] = s.gv[row0 + c];
+        const TV rgv[3] = {ex ? gr[0] : (TV)0, ey ? gr[1] : (TV)0,
+                           ez ? gr[2] + (TV)xs * muv * gr[0] + (TV)ys * muv * gr[1] : (TV)0};
+        float q[1] = {fmaxf(fmaxf(fabsf((float)rgv[0]), fabsf((float)rgv[1])), fabsf((float)rgv[2]))};
+        if (!isfinite(q[0])) q[0] = INFINITY;
+        block_max<1, NW>(q, s.red, tid);
+        prev_stat = stat;
+        stat = q[0];
+        if (stat <= tol || rf >= max_rf || (rf > 0 && !(stat < 0.5f * prev_stat))) break;  // converged / stagnated (uniform)
+        if ((cc & 3) == 0) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) s.rhs[rbM + c] = (float)(-rgv[c]);
+        }
+        __syncthreads();
+        float sum[6];
+        fast_matvec(tile, s.rhs, cc, sum);
+        v3[0] += (TV)(second ? sum[3] : sum[0]);
+        v3[1] += (TV)(second ? sum[4] : sum[1]);
+        v3[2] += (TV)(second ? sum[5] : sum[2]);
+        if (!ex) v3[0] = 0;
+        if (!ey) v3[1] = 0;
+        if (!ez) v3[2] = 0;
+        expand();
+      }
+      // duals from stationarity grad_leg + G_A' y_A = 0, then primal feasibility + dual sign
+#pragma unroll
+      for (int i = 0; i < 5; ++i) yn[i] = 0;
+      viol[0] = viol[1] = viol[2] = 0.f;
+      if (stance) {
+        TV zacc = gr[2];
+        if (xs > 0) { yn[1] = -gr[0]; zacc += muv * (-yn[1]); }
+        else if (xs < 0) { yn[2] = -gr[0]; zacc += muv * yn[2]; }
+        if (ys > 0) { yn[3] = -gr[1]; zacc += muv * (-yn[3]); }
+        else if (ys < 0) { yn[4] = -gr[1]; zacc += muv * yn[4]; }
+        if (zs != 0) yn[0] = -zacc;
+        const TV g0 = uc[2], g1 = uc[0] - muv * uc[2], g2 = uc[0] + muv * uc[2], g3_ = uc[1] - muv * uc[2],
+                 g4 = uc[1] + muv * uc[2];
+        TV pv = fmax(fminv - g0, g0 - fmaxv);
+        pv = fmax(pv, fmax(g1, -g2));
+        pv = fmax(pv, fmax(g3_, -g4));
+        TV dv = fmax(fmax(-yn[1], yn[2]), fmax(-yn[3], yn[4]));
+        if (zs > 0) dv = fmax(dv, -yn[0]);
+        if (zs < 0) dv = fmax(dv, yn[0]);
+        viol[0] = (float)fmax(pv, (TV)0);
+        viol[1] = (float)fmax(dv, (TV)0);
+        viol[2] = fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2]));
+        if (!(isfinite(viol[0]) && isfinite(viol[1]))) viol[0] = viol[1] = INFINITY;
+      }
+      block_max<3, NW>(viol, s.red, tid);
+      if (stg == 0) {
+        const bool plausible = viol[0] <= 1e-2f * fmaxf(1.f, viol[2]) && viol[1] <= 1e-2f * fmaxf(1.f, gmaxf);
+        if (!plausible) break;
+      } else {
+        ok = viol[0] <= ftol * fmaxf(1.f, viol[2]) && viol[1] <= dtol && stat <= acc_stat;
+      }
+    }
+    STAMP(6);
+    ++psteps;
+    if ((cc & 3) == 0) {   // publish the candidate as the next polish iterate / the answer
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { s.pu[row0 + c] = uc[c]; s.uv[row0 + c] = uc[c]; }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) s.py[myleg * 5 + i] = yn[i];
+    }
+    __syncthreads();
+    STAMP(7);
+    if (ok) break;
+  }
+
+  if (!ok && !last) {
+    // not solved this round: OSQP's rho adaptation from the ADMM residuals, then leave the QP in the pipeline
+    if ((cc & 3) == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s.uv[row0 + c] = (TV)s.ua[row0 + c];
+    }
+    __syncthreads();
+    struct_grad<SmemF<TV>, TV, N>(s, tid);
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      const TV U0 = (TV)s.ua[row0], U1 = (TV)s.ua[row0 + 1], U2 = (TV)s.ua[row0 + 2];
+      const TV gu[5] = {U2, U0 - muv * U2, U0 + muv * U2, U1 - muv * U2, U1 + muv * U2};
+      const float* ya = s.ya + myleg * 5;
+      const TV Gy[3] = {(TV)ya[1] + (TV)ya[2], (TV)ya[3] + (TV)ya[4], (TV)ya[0] + muv * (-(TV)ya[1] + (TV)ya[2] - (TV)ya[3] + (TV)ya[4])};
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        q[0] = fmaxf(q[0], fabsf((float)(gu[i] - (TV)s.za[myleg * 5 + i])));
+        q[2] = fmaxf(q[2], fmaxf(fabsf((float)gu[i]), fabsf(s.za[myleg * 5 + i])));
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const TV gr = s.gv[row0 + c];
+        q[1] = fmaxf(q[1], fabsf((float)(gr + Gy[c])));
+        q[3] = fmaxf(q[3], fmaxf(fabsf((float)(gr - s.gl[row0 + c])), fabsf((float)Gy[c])));
+      }
+    }
+    block_max<4, NW>(q, s.red, tid);
+    if (tid == 0) {
+      const float sp = q[2], sd = fmaxf(q[3], gmaxf);
+      const float ratio = sqrtf((q[0] / fmaxf(sp, 1e-12f)) / fmaxf(q[1] / fmaxf(sd, 1e-12f), 1e-30f));
+      float rho = wq[FG::NL * 13];
+      if (isfinite(ratio) && (ratio > 2.f || ratio < 0.5f)) rho = fminf(fmaxf(rho * ratio, 1e-4f), 1e4f);
+      wq[FG::NL * 13] = rho;
+      itersg[b] += 1000 * psteps;
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ outputs (src/mpc.py:265-268)
+  int status = MPCQP_STATUS_SOLVED_POLISHED;
+  float res_p = viol[0], res_d = fmaxf(viol[1], stat);
+  if (!ok) {   // last round: hand back the last ADMM iterate
+    status = MPCQP_STATUS_MAX_ITER;
+    if ((cc & 3) == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s.uv[row0 + c] = (TV)s.ua[row0 + c];
+    }
+  }
+  if ((cc & 3) == 0 && !stance) s.uv[row0] = s.uv[row0 + 1] = s.uv[row0 + 2] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)s.uv[i];
+  if (Xg) {
+    struct_grad<SmemF<TV>, TV, N>(s, tid);
+    for (int i = tid; i < (N + 1) * 13; i += NT) {
+      const int k = i / 13, c = i % 13;
+      const TV v = (c == 12 || k == 0) ? s.x0[c] : s.Xs[k * 12 + c];
+      Xg[b * (N + 1) * 13 + i] = (TIO)v;
+    }
+  }
+  STAMP(8);
+  if (tid == 0) {
+    statusg[b] = status;
+    itersg[b] += 1000 * psteps;
+    if (resg) { resg[2 * b] = res_p; resg[2 * b + 1] = res_d; }
+  }
+}
+
+}  // namespace

@@ -1,0 +1,30 @@
+"""Developer tool: time library variants (same process, interleaved rounds) on the bench workload."""
+import os, sys, time
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import mpcqp
+from mpcqp import _capi
+B = 4096
+batch = mpcqp.synth.config3(B)
+libs = sys.argv[1:] or ["libmpcqp.so"]
+solvers = {}
+for name in libs:
+    _capi._product = _capi.Library(os.path.join(REPO, "mpc-for-dynamic-locomotion-in-the-mit-cheetah-3_amd", "csrc", name.split(":")[0]))
+    kw = {"flags": 1 | 4} if name.endswith(":general") else {}
+    sol = mpcqp.MPCBatch(N=10, precision="mixed", **kw)
+    solvers[name] = (sol, sol.upload(batch))
+res = {k: [] for k in solvers}
+for rnd in range(4):
+    for name, (sol, dev) in solvers.items():
+        for _ in range(3):
+            out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+        torch.cuda.synchronize()
+        res[name].append((time.perf_counter() - t0) / 10 * 1e3)
+        st = out["status"].cpu().numpy()
+for name, v in res.items():
+    print(f"{name:24s} ms/batch median {np.median(v):.3f} min {min(v):.3f}  -> {B / np.median(v) * 1e3:,.0f} QP/s   solved {float(((st==1)|(st==2)).mean()):.4f}")
