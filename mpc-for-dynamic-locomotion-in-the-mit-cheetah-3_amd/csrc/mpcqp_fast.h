@@ -1,12 +1,17 @@
 // mpcqp_fast.h -- fast path for the benchmarked configuration: horizon 10, ADMM + active-set polish, fp32 matrix
 // tiles with fp64 (MIXED) or fp32 (F32) structured residuals.
 //
-// Two kernels per round, chained through a small HBM workspace, instead of one monolithic kernel:
-//   mpcqp_fast_admm    setup -> M = H + diag -> in-register sweep -> K ADMM iterations        (pure fp32)
-//   mpcqp_fast_polish  setup -> active set -> reduced matrix -> sweep -> refined solve -> KKT  (fp32 tiles + TV)
-// Splitting keeps each kernel's register budget separate (no scratch), so several workgroups share a CU; a QP that
-// is solved leaves the pipeline (later rounds exit at the first instruction), the rest get K more iterations with an
-// OSQP-adapted rho and another polish.
+// One kernel, one QP per workgroup, but the phases of the solve are separate NOINLINE device functions that talk to
+// each other only through the workgroup's LDS block (a file-scope __shared__ object, so the callees use plain ds_*
+// addressing):
+//   ph_setup        operator tuple -> per-variable response vectors, linear term g
+//   ph_admm         M = H + sigma I + rho G'G -> register tiles -> in-register sweep -> K ADMM iterations (fp32),
+//                   with one early OSQP rho check (ph_ratio) that rebuilds the matrix for slowly converging QPs
+//   ph_polish_step  active set -> reduced matrix tiles -> sweep -> solve refined against the TV gradient -> KKT
+//   ph_output       forces / predicted states / status
+// Every phase that needs the matrix rebuilds it, so the 6 x 16 register tile is local to a phase and each phase gets
+// its own register allocation: the fp64 polish no longer pushes the fp32 ADMM loop into scratch (and vice versa), and a
+// QP whose polish fails just runs its next ADMM block + polish in place while the rest of the grid moves on.
 //
 // Geometry (n = 120 force variables, 40 leg-stages): thread (g, c) of a 160-thread workgroup (192 launched: the
 // last 32 mirror group 19 so every wave is full) owns rows 6g..6g+5 (two leg-stages) and columns 15c..15c+14 as a
@@ -15,6 +20,12 @@
 // banks (a stride of 16 puts them on two: 4-way conflicts, 60 % of all LDS cycles in the first version).
 #pragma once
 #include "mpcqp_device.h"
+
+// Occupancy target (waves per SIMD) of the fast-path kernel and its phase functions.
+#ifndef MPCQP_FAST_WPE
+#define MPCQP_FAST_WPE 2
+#endif
+#define MPCQP_PHASE __device__ __attribute__((noinline))
 
 namespace {
 
@@ -26,7 +37,6 @@ struct FG {
   static constexpr int NG = n / RT;        // 20 row groups
   static constexpr int NT = 192;           // threads launched (160 + 32 mirrors)
   static constexpr int NW = 3;
-  static constexpr int WS = NL * 13 + 4;   // workspace floats per QP: (u3, z5, y5) per leg-stage + rho + spare
 };
 
 template <typename TV>
@@ -49,8 +59,35 @@ struct SmemF {
   alignas(16) float vbuf[2 * FG::VP];
   alignas(16) float rhs[2 * FG::VP];
   float red[FG::NW * 4];
+  float kkt[4];                             // stat, primal violation, dual violation of the last polish step
+  float gmax;                               // |g|_inf
+  float rho;                                // current ADMM penalty
+  int iters, psteps, hard;                  // bookkeeping shared by the phases
   uint8_t ct[40];
   uint8_t em[40];
+};
+
+// The workgroup's LDS block.  File scope so that the noinline phase functions address it directly (ds_*).
+__shared__ SmemF<float> g_lds_f;
+__shared__ SmemF<double> g_lds_d;
+template <typename TV> __device__ __forceinline__ SmemF<TV>& lds();
+template <> __device__ __forceinline__ SmemF<float>& lds<float>() { return g_lds_f; }
+template <> __device__ __forceinline__ SmemF<double>& lds<double>() { return g_lds_d; }
+
+struct Lane {   // who am I inside the workgroup
+  int tid, grp, cc, myleg, row0, rbA, rbB, rbM;
+  bool second;
+  __device__ __forceinline__ Lane() {
+    tid = threadIdx.x;
+    grp = min(tid / 8, FG::NG - 1);   // threads 160..191 mirror group 19 (full waves, identical writes)
+    cc = tid % 8;
+    second = cc >= 4;                 // lanes 0-3 look after leg-stage 2g, lanes 4-7 after 2g+1
+    myleg = 2 * grp + (second ? 1 : 0);
+    row0 = 3 * myleg;
+    rbA = (6 * grp / FG::CW) * FG::S + (6 * grp) % FG::CW;
+    rbB = ((6 * grp + 3) / FG::CW) * FG::S + (6 * grp + 3) % FG::CW;
+    rbM = second ? rbB : rbA;
+  }
 };
 
 __device__ __forceinline__ int fpidx(int i) { return (i / FG::CW) * FG::S + i % FG::CW; }
@@ -256,60 +293,19 @@ __device__ __forceinline__ void fast_describe(SmemF<TV>& s, int myleg, int a, bo
   }
 }
 
-// ------------------------------------------------------------------------------------------------------ kernel A
-template <typename TIO>
-__global__ void __launch_bounds__(FG::NT)
-mpcqp_fast_admm(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const TIO* __restrict__ x0g,
-                const TIO* __restrict__ rg, const uint8_t* __restrict__ cg, const TIO* __restrict__ xdg,
-                const TIO* __restrict__ mug, TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __restrict__ statusg,
-                int* __restrict__ itersg, float* __restrict__ resg, float* __restrict__ ws, int first) {
-  constexpr int N = FG::N, n = FG::n, NT = FG::NT, S = FG::S, VP = FG::VP;
-  const size_t b = blockIdx.x;
-  if (!first && statusg[b] != MPCQP_STATUS_UNSOLVED) return;   // solved (or flagged) in an earlier round
-  __shared__ SmemF<float> s;
-  const DevCfg& cfg = *cfgp;
-  const int tid = threadIdx.x;
-  const int grp = min(tid / 8, FG::NG - 1);   // threads 160..191 mirror group 19 (full waves, identical writes)
-  const int cc = tid % 8;
-  const bool second = cc >= 4;                // lanes 0-3 look after leg-stage 2g, lanes 4-7 after 2g+1
-  const int myleg = 2 * grp + (second ? 1 : 0);
-  const int rbA = fpidx(6 * grp), rbB = fpidx(6 * grp + 3);
-  const int rbM = second ? rbB : rbA;
-  STAMP_INIT
-  if (fast_setup<float, TIO>(s, cfg, ctab, x0g, rg, cg, xdg, mug, b, tid)) {
-    for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
-    if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (N + 1) * 13 + i] = (TIO)0;
-    if (tid == 0) {
-      statusg[b] = MPCQP_STATUS_NONFINITE;
-      itersg[b] = 0;
-      if (resg) { resg[2 * b] = 0.f; resg[2 * b + 1] = 0.f; }
-    }
-    return;
-  }
-  float* wq = ws + b * FG::WS;
-  const bool stance = s.ct[myleg] != 0;
-  const float mu = s.mu;
-  const float rho = first ? (float)cfg.rho : wq[FG::NL * 13];
-  const float sigma = (float)cfg.sigma, relax = (float)cfg.relax;
-  STAMP(0);
-  fast_describe<float>(s, myleg, cc & 3, stance, mu, 0, rho, sigma, 0, 0, 0);
-  __syncthreads();
-  STAMP(1);
-  float tile[6][16];
-  fast_build<float>(tile, s, grp, cc);
-  STAMP(2);
-  fast_sweep<float>(tile, s, grp, cc, rbA, rbB);
-  STAMP(3);
-
-  // ADMM (OSQP algorithm 1) on the rows  fz | fx - mu fz | fx + mu fz | fy - mu fz | fy + mu fz  of my leg-stage
+// ------------------------------------------------------------------------------------------------------ ADMM block
+// `iters` iterations of OSQP algorithm 1 on the rows  fz | fx - mu fz | fx + mu fz | fy - mu fz | fy + mu fz  of my
+// leg-stage (src/mpc.py:138-173).  State (u, z, y) in registers, right-hand sides double-buffered in LDS, one barrier
+// per iteration.  tile = -M^{-1}.
+template <typename TV>
+__device__ __forceinline__ void fast_admm_iters(const float (&tile)[6][16], SmemF<TV>& s, const int iters, const float rho,
+                                                const float sigma, const float relax, const float mu, const bool stance,
+                                                const float fmin, const float fmax, const float (&g3)[3], float (&u3)[3],
+                                                float (&z5)[5], float (&y5)[5], const int cc, const bool second, const int rbM) {
+  constexpr int VP = FG::VP;
   const float BIG = 1e30f;
-  const float lo0 = stance ? (float)cfg.fmin : 0.f, hi0 = stance ? (float)cfg.fmax : 0.f;   // src/mpc.py:151-157
-  const float hiP = stance ? BIG : 0.f, loM = stance ? -BIG : 0.f;                         // src/mpc.py:159-173
-  float g3[3], u3[3], z5[5], y5[5];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { g3[c] = s.gl[3 * myleg + c]; u3[c] = first ? 0.f : wq[myleg * 13 + c]; }
-#pragma unroll
-  for (int i = 0; i < 5; ++i) { z5[i] = first ? 0.f : wq[myleg * 13 + 3 + i]; y5[i] = first ? 0.f : wq[myleg * 13 + 8 + i]; }
+  const float lo0 = stance ? fmin : 0.f, hi0 = stance ? fmax : 0.f;   // src/mpc.py:151-157
+  const float hiP = stance ? BIG : 0.f, loM = stance ? -BIG : 0.f;   // src/mpc.py:159-173
   const float inv_rho = 1.f / rho;
   auto write_rhs = [&](int bsel) {
     float v[5];
@@ -324,9 +320,8 @@ mpcqp_fast_admm(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab
   };
   write_rhs(0);
   __syncthreads();
-  const int K = cfg.check_every;
   int buf = 0;
-  for (int it = 0; it < K; ++it) {
+  for (int it = 0; it < iters; ++it) {
     float sum[6];
     fast_matvec(tile, s.rhs + buf * VP, cc, sum);
     const float ut[3] = {second ? sum[3] : sum[0], second ? sum[4] : sum[1], second ? sum[5] : sum[2]};
@@ -346,255 +341,300 @@ mpcqp_fast_admm(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab
     write_rhs(buf);
     __syncthreads();
   }
-  STAMP(4);
-  if ((cc & 3) == 0 && tid < FG::NG * 8) {   // park (u, z, y) of my leg-stage for the polish kernel / the next round
-#pragma unroll
-    for (int c = 0; c < 3; ++c) wq[myleg * 13 + c] = u3[c];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { wq[myleg * 13 + 3 + i] = z5[i]; wq[myleg * 13 + 8 + i] = y5[i]; }
-  }
-  if (tid == 0) {
-    wq[FG::NL * 13] = rho;
-    if (first) { statusg[b] = MPCQP_STATUS_UNSOLVED; itersg[b] = K; }
-    else itersg[b] += K;
-  }
-  STAMP(5);
 }
 
-// ------------------------------------------------------------------------------------------------------ kernel B
+constexpr int ADAPT_AT = 25;             // iteration of the single early rho check
+constexpr float ADAPT_THR = 10.f, ADAPT_RHO_MAX = 30.f;
+constexpr int HARD_ITER_FACTOR = 3;      // ADMM block length of the QPs that trigger it (x check_every)
+constexpr int HARD_POLISH_FACTOR = 2;    // ... and their polish-step budget (x polish_max)
+
+// ------------------------------------------------------------------------------------------------------ phases
 template <typename TV, typename TIO>
-__global__ void __launch_bounds__(FG::NT)
-mpcqp_fast_polish(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const TIO* __restrict__ x0g,
-                  const TIO* __restrict__ rg, const uint8_t* __restrict__ cg, const TIO* __restrict__ xdg,
-                  const TIO* __restrict__ mug, TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __restrict__ statusg,
-                  int* __restrict__ itersg, float* __restrict__ resg, float* __restrict__ ws, int last) {
-  constexpr int N = FG::N, n = FG::n, NT = FG::NT, NW = FG::NW;
-  const size_t b = blockIdx.x;
-  if (statusg[b] != MPCQP_STATUS_UNSOLVED) return;
-  __shared__ SmemF<TV> s;
-  const DevCfg& cfg = *cfgp;
+MPCQP_PHASE int ph_setup(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const TIO* __restrict__ x0g,
+                         const TIO* __restrict__ rg, const uint8_t* __restrict__ cg, const TIO* __restrict__ xdg,
+                         const TIO* __restrict__ mug, size_t b) {
+  SmemF<TV>& s = lds<TV>();
   const int tid = threadIdx.x;
-  const int grp = min(tid / 8, FG::NG - 1);
-  const int cc = tid % 8;
-  const bool second = cc >= 4;
-  const int myleg = 2 * grp + (second ? 1 : 0);
-  const int row0 = 3 * myleg;
-  const int rbA = fpidx(6 * grp), rbB = fpidx(6 * grp + 3);
-  const int rbM = second ? rbB : rbA;
-  STAMP_INIT
-  float* wq = ws + b * FG::WS;
-  for (int i = tid; i < FG::NL; i += NT) {   // last ADMM iterate -> LDS
+  if (fast_setup<TV, TIO>(s, *cfgp, ctab, x0g, rg, cg, xdg, mug, b, tid)) return 1;
+  for (int i = tid; i < FG::n; i += FG::NT) { s.ua[i] = 0.f; s.pu[i] = (TV)0; }
+  for (int i = tid; i < FG::NL * 5; i += FG::NT) { s.za[i] = 0.f; s.ya[i] = 0.f; s.py[i] = (TV)0; }
+  float q[1] = {tid < FG::n ? fabsf((float)s.gl[tid]) : 0.f};
+  block_max<1, FG::NW>(q, s.red, tid);
+  if (tid == 0) { s.gmax = q[0]; s.rho = (float)cfgp->rho; s.iters = 0; s.psteps = 0; s.hard = 0; }
+  __syncthreads();
+  return 0;
+}
+
+// OSQP's rho-adaptation ratio sqrt((|r_prim| / norm_prim) / (|r_dual| / norm_dual)) of the ADMM iterate in
+// s.ua / s.za / s.ya.  Uniform result.
+template <typename TV>
+MPCQP_PHASE float ph_ratio() {
+  constexpr int N = FG::N, NW = FG::NW;
+  SmemF<TV>& s = lds<TV>();
+  const Lane L;
+  const int tid = L.tid, myleg = L.myleg, row0 = L.row0;
+  const TV muv = s.mu;
+  if ((L.cc & 3) == 0) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { const float v = wq[i * 13 + c]; s.ua[3 * i + c] = v; s.pu[3 * i + c] = (TV)v; }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { s.za[5 * i + k] = wq[i * 13 + 3 + k]; const float y = wq[i * 13 + 8 + k]; s.ya[5 * i + k] = y; s.py[5 * i + k] = (TV)y; }
+    for (int c = 0; c < 3; ++c) s.uv[row0 + c] = (TV)s.ua[row0 + c];
   }
-  (void)fast_setup<TV, TIO>(s, cfg, ctab, x0g, rg, cg, xdg, mug, b, tid);   // inputs were screened by the ADMM kernel
+  __syncthreads();
+  struct_grad<SmemF<TV>, TV, N>(s, tid);
+  float q[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    const TV U0 = (TV)s.ua[row0], U1 = (TV)s.ua[row0 + 1], U2 = (TV)s.ua[row0 + 2];
+    const TV gu[5] = {U2, U0 - muv * U2, U0 + muv * U2, U1 - muv * U2, U1 + muv * U2};
+    const float* ya = s.ya + myleg * 5;
+    const TV Gy[3] = {(TV)ya[1] + (TV)ya[2], (TV)ya[3] + (TV)ya[4], (TV)ya[0] + muv * (-(TV)ya[1] + (TV)ya[2] - (TV)ya[3] + (TV)ya[4])};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      q[0] = fmaxf(q[0], fabsf((float)(gu[i] - (TV)s.za[myleg * 5 + i])));
+      q[2] = fmaxf(q[2], fmaxf(fabsf((float)gu[i]), fabsf(s.za[myleg * 5 + i])));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const TV gr = s.gv[row0 + c];
+      q[1] = fmaxf(q[1], fabsf((float)(gr + Gy[c])));
+      q[3] = fmaxf(q[3], fmaxf(fabsf((float)(gr - s.gl[row0 + c])), fabsf((float)Gy[c])));
+    }
+  }
+  block_max<4, NW>(q, s.red, tid);
+  const float sp = q[2], sd = fmaxf(q[3], s.gmax);
+  return sqrtf((q[0] / fmaxf(sp, 1e-12f)) / fmaxf(q[1] / fmaxf(sd, 1e-12f), 1e-30f));
+}
+
+// One ADMM block from the state in s.ua / s.za / s.ya with penalty s.rho: matrix tiles -> sweep -> iterations.
+// `adapt`: run the single early rho check (round 0 only); a QP that triggers it gets rho <- rho * ratio, a rebuilt
+// matrix and a longer block.  Updates s.rho / s.iters / s.hard and leaves the new iterate in s.ua/za/ya and s.pu/py.
+template <typename TV>
+MPCQP_PHASE void ph_admm(const DevCfg* __restrict__ cfgp, const int adapt) {
+  SmemF<TV>& s = lds<TV>();
+  const DevCfg& cfg = *cfgp;
+  const Lane L;
+  const bool stance = s.ct[L.myleg] != 0;
+  const float mu = (float)s.mu, sigma = (float)cfg.sigma, relax = (float)cfg.relax;
+  const float fmin = (float)s.cf.fmin, fmax = (float)s.cf.fmax;
+  float rho = s.rho;
+  float g3[3], u3[3], z5[5], y5[5];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { g3[c] = (float)s.gl[L.row0 + c]; u3[c] = s.ua[L.row0 + c]; }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { z5[i] = s.za[5 * L.myleg + i]; y5[i] = s.ya[5 * L.myleg + i]; }
+  int K = cfg.check_every;
+  int it = 0, seg_end = (adapt && ADAPT_AT < K) ? ADAPT_AT : K;
+  bool need_build = true;
+  int hard = 0;
+  float tile[6][16];
+  STAMP_INIT
+  for (;;) {
+    if (need_build) {
+      __syncthreads();
+      fast_describe<TV>(s, L.myleg, L.cc & 3, stance, s.mu, 0, rho, sigma, 0, 0, 0);
+      __syncthreads();
+      STAMP(1);
+      fast_build<TV>(tile, s, L.grp, L.cc);
+      STAMP(2);
+      fast_sweep<TV>(tile, s, L.grp, L.cc, L.rbA, L.rbB);
+      STAMP(3);
+      need_build = false;
+    }
+    fast_admm_iters<TV>(tile, s, seg_end - it, rho, sigma, relax, mu, stance, fmin, fmax, g3, u3, z5, y5, L.cc, L.second, L.rbM);
+    it = seg_end;
+    STAMP(4);
+    if ((L.cc & 3) == 0) {   // publish the iterate
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { s.ua[L.row0 + c] = u3[c]; s.pu[L.row0 + c] = (TV)u3[c]; }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { s.za[5 * L.myleg + i] = z5[i]; s.ya[5 * L.myleg + i] = y5[i]; s.py[5 * L.myleg + i] = (TV)y5[i]; }
+    }
+    __syncthreads();
+    if (it >= K) break;
+    const float ratio = ph_ratio<TV>();   // separate register allocation; the tile is saved around the call
+    if (ratio > ADAPT_THR) {              // uniform
+      rho = fminf(rho * ratio, ADAPT_RHO_MAX);
+      need_build = true;
+      hard = 1;
+      K = min(HARD_ITER_FACTOR * K, cfg.max_iter);
+    }
+    seg_end = K;
+    STAMP(5);
+  }
+  if (L.tid == 0) { s.rho = rho; s.iters += K; s.hard |= hard; }
+  __syncthreads();
+}
+
+// One active-set polish step from the iterate (s.pu, s.py): returns 1 when the refined equality-constrained solve passes
+// the KKT check (answer in s.uv), else 0 with (s.pu, s.py) replaced by the candidate for the next step.
+template <typename TV>
+MPCQP_PHASE int ph_polish_step() {
+  constexpr int N = FG::N, NW = FG::NW;
+  SmemF<TV>& s = lds<TV>();
+  const Lane L;
+  const int tid = L.tid, grp = L.grp, cc = L.cc, myleg = L.myleg, row0 = L.row0, rbA = L.rbA, rbB = L.rbB, rbM = L.rbM;
+  const bool second = L.second;
   const bool stance = s.ct[myleg] != 0;
   const TV muv = s.mu;
   const TV fminv = s.cf.fmin, fmaxv = s.cf.fmax;
-  float gmaxf;
-  {
-    float q[1] = {fmaxf(fmaxf(fabsf((float)s.gl[row0]), fabsf((float)s.gl[row0 + 1])), fabsf((float)s.gl[row0 + 2]))};
-    block_max<1, NW>(q, s.red, tid);
-    gmaxf = q[0];
-  }
+  const float gmaxf = s.gmax;
   const float tol_stat = (sizeof(TV) == 8) ? (1e-6f + 1e-9f * gmaxf) : (3e-7f * fmaxf(gmaxf, 1.f));
   const float acc_stat = (sizeof(TV) == 8) ? (1e-5f + 1e-8f * gmaxf) : (1e-5f * fmaxf(gmaxf, 1.f));
   const float ftol = (sizeof(TV) == 8) ? 1e-7f : 2e-5f;
   // dual-sign slack must stay well below alpha-curvature * force tolerance (a wrongly active row with multiplier -e
   // moves the forces by ~e / (2 alpha))
   const float dtol = (sizeof(TV) == 8) ? (1e-5f + 1e-9f * gmaxf) : (2e-5f * fmaxf(1.f, gmaxf));
-  const int polish_max = cfg.polish_max;
-  int psteps = 0;
   bool ok = false;
   float stat = INFINITY, viol[3] = {0.f, 0.f, 0.f};
-  STAMP(0);
   float tile[6][16];
-
-  for (int ps = 0; ps < polish_max; ++ps) {
-    // primal-dual active-set rule on (pu, py): rows 0 fz | 1 fx - mu fz <= 0 | 2 fx + mu fz >= 0 | 3,4 same for fy
-    int zs = 0, xs = 0, ys = 0;
-    if (stance) {
-      const TV u0 = s.pu[row0], u1 = s.pu[row0 + 1], u2 = s.pu[row0 + 2];
-      const TV y0 = s.py[myleg * 5], y1 = s.py[myleg * 5 + 1], y2 = s.py[myleg * 5 + 2], y3 = s.py[myleg * 5 + 3], y4 = s.py[myleg * 5 + 4];
-      const TV g1 = u0 - muv * u2, g2 = u0 + muv * u2, g3_ = u1 - muv * u2, g4 = u1 + muv * u2;
-      if (y0 + (u2 - fmaxv) > 0) zs = 1;
-      else if (y0 + (u2 - fminv) < 0) zs = -1;
-      const bool hx = y1 + g1 > 0, lx = y2 + g2 < 0;
-      if (hx && lx) xs = (g1 > -g2) ? 1 : -1; else if (hx) xs = 1; else if (lx) xs = -1;
-      const bool hy = y3 + g3_ > 0, ly = y4 + g4 < 0;
-      if (hy && ly) ys = (g3_ > -g4) ? 1 : -1; else if (hy) ys = 1; else if (ly) ys = -1;
-    }
-    const bool ez = stance && zs == 0, ex = stance && xs == 0, ey = stance && ys == 0;
-    TV up3[3] = {0, 0, 0};
-    if (stance && zs != 0) {
-      const TV F = zs > 0 ? fmaxv : fminv;
-      up3[2] = F;
-      if (xs) up3[0] = (TV)xs * muv * F;
-      if (ys) up3[1] = (TV)ys * muv * F;
-    }
-    TV v3[3] = {ex ? s.pu[row0] : (TV)0, ey ? s.pu[row0 + 1] : (TV)0, ez ? s.pu[row0 + 2] : (TV)0};
-    __syncthreads();   // everyone has read pu / py of this round before pq / em are rewritten
-    fast_describe<TV>(s, myleg, cc & 3, stance, muv, 1, 0.f, 0.f, zs, xs, ys);
-    __syncthreads();
-    STAMP(1);
-    fast_build<TV>(tile, s, grp, cc);
-    STAMP(2);
-    fast_sweep<TV>(tile, s, grp, cc, rbA, rbB);
-    STAMP(3);
-
-    TV uc[3];
-    auto expand = [&]() {
-      uc[0] = up3[0]; uc[1] = up3[1]; uc[2] = up3[2];
-      if (ez) {
-        uc[2] = v3[2];
-        if (xs) uc[0] = (TV)xs * muv * v3[2];
-        if (ys) uc[1] = (TV)ys * muv * v3[2];
-      }
-      if (ex) uc[0] = v3[0];
-      if (ey) uc[1] = v3[1];
-    };
-    expand();
-    float prev_stat = INFINITY;
-    stat = INFINITY;
-    TV yn[5];
-    ok = false;
-    // stage 0: two refinement rounds, then a loose KKT screen; only a plausible candidate is refined to the tight
-    // tolerance (stage 1) and checked for real.  Wrong active sets are dropped early.
-    for (int stg = 0; stg < 2; ++stg) {
-      const float tol = stg == 0 ? fmaxf(tol_stat, 1e-3f * fmaxf(gmaxf, 1.f)) : tol_stat;
-      const int max_rf = stg == 0 ? 2 : 10;
-      TV gr[3] = {0, 0, 0};
-      for (int rf = 0;; ++rf) {
-        if ((cc & 3) == 0) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) s.uv[row0 + c] = uc[c];
-        }
-        __syncthreads();
-        struct_grad<SmemF<TV>, TV, N>(s, tid);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gr[c] = s.gv[row0 + c];
-        const TV rgv[3] = {ex ? gr[0] : (TV)0, ey ? gr[1] : (TV)0,
-                           ez ? gr[2] + (TV)xs * muv * gr[0] + (TV)ys * muv * gr[1] : (TV)0};
-        float q[1] = {fmaxf(fmaxf(fabsf((float)rgv[0]), fabsf((float)rgv[1])), fabsf((float)rgv[2]))};
-        if (!isfinite(q[0])) q[0] = INFINITY;
-        block_max<1, NW>(q, s.red, tid);
-        prev_stat = stat;
-        stat = q[0];
-        if (stat <= tol || rf >= max_rf || (rf > 0 && !(stat < 0.5f * prev_stat))) break;  // converged / stagnated (uniform)
-        if ((cc & 3) == 0) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) s.rhs[rbM + c] = (float)(-rgv[c]);
-        }
-        __syncthreads();
-        float sum[6];
-        fast_matvec(tile, s.rhs, cc, sum);
-        v3[0] += (TV)(second ? sum[3] : sum[0]);
-        v3[1] += (TV)(second ? sum[4] : sum[1]);
-        v3[2] += (TV)(second ? sum[5] : sum[2]);
-        if (!ex) v3[0] = 0;
-        if (!ey) v3[1] = 0;
-        if (!ez) v3[2] = 0;
-        expand();
-      }
-      // duals from stationarity grad_leg + G_A' y_A = 0, then primal feasibility + dual sign
-#pragma unroll
-      for (int i = 0; i < 5; ++i) yn[i] = 0;
-      viol[0] = viol[1] = viol[2] = 0.f;
-      if (stance) {
-        TV zacc = gr[2];
-        if (xs > 0) { yn[1] = -gr[0]; zacc += muv * (-yn[1]); }
-        else if (xs < 0) { yn[2] = -gr[0]; zacc += muv * yn[2]; }
-        if (ys > 0) { yn[3] = -gr[1]; zacc += muv * (-yn[3]); }
-        else if (ys < 0) { yn[4] = -gr[1]; zacc += muv * yn[4]; }
-        if (zs != 0) yn[0] = -zacc;
-        const TV g0 = uc[2], g1 = uc[0] - muv * uc[2], g2 = uc[0] + muv * uc[2], g3_ = uc[1] - muv * uc[2],
-                 g4 = uc[1] + muv * uc[2];
-        TV pv = fmax(fminv - g0, g0 - fmaxv);
-        pv = fmax(pv, fmax(g1, -g2));
-        pv = fmax(pv, fmax(g3_, -g4));
-        TV dv = fmax(fmax(-yn[1], yn[2]), fmax(-yn[3], yn[4]));
-        if (zs > 0) dv = fmax(dv, -yn[0]);
-        if (zs < 0) dv = fmax(dv, yn[0]);
-        viol[0] = (float)fmax(pv, (TV)0);
-        viol[1] = (float)fmax(dv, (TV)0);
-        viol[2] = fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2]));
-        if (!(isfinite(viol[0]) && isfinite(viol[1]))) viol[0] = viol[1] = INFINITY;
-      }
-      block_max<3, NW>(viol, s.red, tid);
-      if (stg == 0) {
-        const bool plausible = viol[0] <= 1e-2f * fmaxf(1.f, viol[2]) && viol[1] <= 1e-2f * fmaxf(1.f, gmaxf);
-        if (!plausible) break;
-      } else {
-        ok = viol[0] <= ftol * fmaxf(1.f, viol[2]) && viol[1] <= dtol && stat <= acc_stat;
-      }
-    }
-    STAMP(6);
-    ++psteps;
-    if ((cc & 3) == 0) {   // publish the candidate as the next polish iterate / the answer
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { s.pu[row0 + c] = uc[c]; s.uv[row0 + c] = uc[c]; }
-#pragma unroll
-      for (int i = 0; i < 5; ++i) s.py[myleg * 5 + i] = yn[i];
-    }
-    __syncthreads();
-    STAMP(7);
-    if (ok) break;
+  STAMP_INIT
+  {
+  // primal-dual active-set rule on (pu, py): rows 0 fz | 1 fx - mu fz <= 0 | 2 fx + mu fz >= 0 | 3,4 same for fy
+  int zs = 0, xs = 0, ys = 0;
+  if (stance) {
+    const TV u0 = s.pu[row0], u1 = s.pu[row0 + 1], u2 = s.pu[row0 + 2];
+    const TV y0 = s.py[myleg * 5], y1 = s.py[myleg * 5 + 1], y2 = s.py[myleg * 5 + 2], y3 = s.py[myleg * 5 + 3], y4 = s.py[myleg * 5 + 4];
+    const TV g1 = u0 - muv * u2, g2 = u0 + muv * u2, g3_ = u1 - muv * u2, g4 = u1 + muv * u2;
+    if (y0 + (u2 - fmaxv) > 0) zs = 1;
+    else if (y0 + (u2 - fminv) < 0) zs = -1;
+    const bool hx = y1 + g1 > 0, lx = y2 + g2 < 0;
+    if (hx && lx) xs = (g1 > -g2) ? 1 : -1; else if (hx) xs = 1; else if (lx) xs = -1;
+    const bool hy = y3 + g3_ > 0, ly = y4 + g4 < 0;
+    if (hy && ly) ys = (g3_ > -g4) ? 1 : -1; else if (hy) ys = 1; else if (ly) ys = -1;
   }
-
-  if (!ok && !last) {
-    // not solved this round: OSQP's rho adaptation from the ADMM residuals, then leave the QP in the pipeline
-    if ((cc & 3) == 0) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) s.uv[row0 + c] = (TV)s.ua[row0 + c];
-    }
-    __syncthreads();
-    struct_grad<SmemF<TV>, TV, N>(s, tid);
-    float q[4] = {0.f, 0.f, 0.f, 0.f};
-    {
-      const TV U0 = (TV)s.ua[row0], U1 = (TV)s.ua[row0 + 1], U2 = (TV)s.ua[row0 + 2];
-      const TV gu[5] = {U2, U0 - muv * U2, U0 + muv * U2, U1 - muv * U2, U1 + muv * U2};
-      const float* ya = s.ya + myleg * 5;
-      const TV Gy[3] = {(TV)ya[1] + (TV)ya[2], (TV)ya[3] + (TV)ya[4], (TV)ya[0] + muv * (-(TV)ya[1] + (TV)ya[2] - (TV)ya[3] + (TV)ya[4])};
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        q[0] = fmaxf(q[0], fabsf((float)(gu[i] - (TV)s.za[myleg * 5 + i])));
-        q[2] = fmaxf(q[2], fmaxf(fabsf((float)gu[i]), fabsf(s.za[myleg * 5 + i])));
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const TV gr = s.gv[row0 + c];
-        q[1] = fmaxf(q[1], fabsf((float)(gr + Gy[c])));
-        q[3] = fmaxf(q[3], fmaxf(fabsf((float)(gr - s.gl[row0 + c])), fabsf((float)Gy[c])));
-      }
-    }
-    block_max<4, NW>(q, s.red, tid);
-    if (tid == 0) {
-      const float sp = q[2], sd = fmaxf(q[3], gmaxf);
-      const float ratio = sqrtf((q[0] / fmaxf(sp, 1e-12f)) / fmaxf(q[1] / fmaxf(sd, 1e-12f), 1e-30f));
-      float rho = wq[FG::NL * 13];
-      if (isfinite(ratio) && (ratio > 2.f || ratio < 0.5f)) rho = fminf(fmaxf(rho * ratio, 1e-4f), 1e4f);
-      wq[FG::NL * 13] = rho;
-      itersg[b] += 1000 * psteps;
-    }
-    return;
+  const bool ez = stance && zs == 0, ex = stance && xs == 0, ey = stance && ys == 0;
+  TV up3[3] = {0, 0, 0};
+  if (stance && zs != 0) {
+    const TV F = zs > 0 ? fmaxv : fminv;
+    up3[2] = F;
+    if (xs) up3[0] = (TV)xs * muv * F;
+    if (ys) up3[1] = (TV)ys * muv * F;
   }
-
-  // ------------------------------------------------------------------ outputs (src/mpc.py:265-268)
-  int status = MPCQP_STATUS_SOLVED_POLISHED;
-  float res_p = viol[0], res_d = fmaxf(viol[1], stat);
-  if (!ok) {   // last round: hand back the last ADMM iterate
-    status = MPCQP_STATUS_MAX_ITER;
-    if ((cc & 3) == 0) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) s.uv[row0 + c] = (TV)s.ua[row0 + c];
-    }
-  }
-  if ((cc & 3) == 0 && !stance) s.uv[row0] = s.uv[row0 + 1] = s.uv[row0 + 2] = 0;
+  TV v3[3] = {ex ? s.pu[row0] : (TV)0, ey ? s.pu[row0 + 1] : (TV)0, ez ? s.pu[row0 + 2] : (TV)0};
+  __syncthreads();   // everyone has read pu / py of this round before pq / em are rewritten
+  fast_describe<TV>(s, myleg, cc & 3, stance, muv, 1, 0.f, 0.f, zs, xs, ys);
   __syncthreads();
-  for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)s.uv[i];
-  if (Xg) {
+  STAMP(1);
+  fast_build<TV>(tile, s, grp, cc);
+  STAMP(2);
+  fast_sweep<TV>(tile, s, grp, cc, rbA, rbB);
+  STAMP(3);
+
+  TV uc[3];
+  auto expand = [&]() {
+    uc[0] = up3[0]; uc[1] = up3[1]; uc[2] = up3[2];
+    if (ez) {
+      uc[2] = v3[2];
+      if (xs) uc[0] = (TV)xs * muv * v3[2];
+      if (ys) uc[1] = (TV)ys * muv * v3[2];
+    }
+    if (ex) uc[0] = v3[0];
+    if (ey) uc[1] = v3[1];
+  };
+  expand();
+  float prev_stat = INFINITY;
+  stat = INFINITY;
+  TV yn[5];
+  ok = false;
+  // stage 0: two refinement rounds, then a loose KKT screen; only a plausible candidate is refined to the tight
+  // tolerance (stage 1) and checked for real.  Wrong active sets are dropped early.
+  for (int stg = 0; stg < 2; ++stg) {
+    const float tol = stg == 0 ? fmaxf(tol_stat, 1e-3f * fmaxf(gmaxf, 1.f)) : tol_stat;
+    const int max_rf = stg == 0 ? 2 : 10;
+    TV gr[3] = {0, 0, 0};
+    for (int rf = 0;; ++rf) {
+      if ((cc & 3) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s.uv[row0 + c] = uc[c];
+      }
+      __syncthreads();
+      struct_grad<SmemF<TV>, TV, N>(s, tid);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gr[c] = s.gv[row0 + c];
+      const TV rgv[3] = {ex ? gr[0] : (TV)0, ey ? gr[1] : (TV)0,
+                         ez ? gr[2] + (TV)xs * muv * gr[0] + (TV)ys * muv * gr[1] : (TV)0};
+      float q[1] = {fmaxf(fmaxf(fabsf((float)rgv[0]), fabsf((float)rgv[1])), fabsf((float)rgv[2]))};
+      if (!isfinite(q[0])) q[0] = INFINITY;
+      block_max<1, NW>(q, s.red, tid);
+      prev_stat = stat;
+      stat = q[0];
+      if (stat <= tol || rf >= max_rf || (rf > 0 && !(stat < 0.5f * prev_stat))) break;  // converged / stagnated (uniform)
+      if ((cc & 3) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s.rhs[rbM + c] = (float)(-rgv[c]);
+      }
+      __syncthreads();
+      float sum[6];
+      fast_matvec(tile, s.rhs, cc, sum);
+      v3[0] += (TV)(second ? sum[3] : sum[0]);
+      v3[1] += (TV)(second ? sum[4] : sum[1]);
+      v3[2] += (TV)(second ? sum[5] : sum[2]);
+      if (!ex) v3[0] = 0;
+      if (!ey) v3[1] = 0;
+      if (!ez) v3[2] = 0;
+      expand();
+    }
+    // duals from stationarity grad_leg + G_A' y_A = 0, then primal feasibility + dual sign
+#pragma unroll
+    for (int i = 0; i < 5; ++i) yn[i] = 0;
+    viol[0] = viol[1] = viol[2] = 0.f;
+    if (stance) {
+      TV zacc = gr[2];
+      if (xs > 0) { yn[1] = -gr[0]; zacc += muv * (-yn[1]); }
+      else if (xs < 0) { yn[2] = -gr[0]; zacc += muv * yn[2]; }
+      if (ys > 0) { yn[3] = -gr[1]; zacc += muv * (-yn[3]); }
+      else if (ys < 0) { yn[4] = -gr[1]; zacc += muv * yn[4]; }
+      if (zs != 0) yn[0] = -zacc;
+      const TV g0 = uc[2], g1 = uc[0] - muv * uc[2], g2 = uc[0] + muv * uc[2], g3_ = uc[1] - muv * uc[2],
+               g4 = uc[1] + muv * uc[2];
+      TV pv = fmax(fminv - g0, g0 - fmaxv);
+      pv = fmax(pv, fmax(g1, -g2));
+      pv = fmax(pv, fmax(g3_, -g4));
+      TV dv = fmax(fmax(-yn[1], yn[2]), fmax(-yn[3], yn[4]));
+      if (zs > 0) dv = fmax(dv, -yn[0]);
+      if (zs < 0) dv = fmax(dv, yn[0]);
+      viol[0] = (float)fmax(pv, (TV)0);
+      viol[1] = (float)fmax(dv, (TV)0);
+      viol[2] = fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2]));
+      if (!(isfinite(viol[0]) && isfinite(viol[1]))) viol[0] = viol[1] = INFINITY;
+    }
+    block_max<3, NW>(viol, s.red, tid);
+    if (stg == 0) {
+      const bool plausible = viol[0] <= 1e-2f * fmaxf(1.f, viol[2]) && viol[1] <= 1e-2f * fmaxf(1.f, gmaxf);
+      if (!plausible) break;
+    } else {
+      ok = viol[0] <= ftol * fmaxf(1.f, viol[2]) && viol[1] <= dtol && stat <= acc_stat;
+    }
+  }
+  STAMP(6);
+  if ((cc & 3) == 0) {   // publish the candidate as the next polish iterate / the answer
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s.pu[row0 + c] = uc[c]; s.uv[row0 + c] = uc[c]; }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s.py[myleg * 5 + i] = yn[i];
+  }
+  __syncthreads();
+    STAMP(7);
+  }
+  if (tid == 0) { s.kkt[0] = stat; s.kkt[1] = viol[0]; s.kkt[2] = viol[1]; s.psteps += 1; }
+  __syncthreads();
+  return ok ? 1 : 0;
+}
+
+template <typename TV, typename TIO>
+MPCQP_PHASE void ph_output(TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __restrict__ statusg, int* __restrict__ itersg,
+                           float* __restrict__ resg, const size_t b, const int ok) {
+  constexpr int N = FG::N, n = FG::n, NT = FG::NT;
+  SmemF<TV>& s = lds<TV>();
+  const Lane L;
+  const int tid = L.tid, row0 = L.row0;
+  const bool stance = s.ct[L.myleg] != 0;
+  if (!ok && (L.cc & 3) == 0) {   // iteration cap: hand back the last ADMM iterate
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s.uv[row0 + c] = (TV)s.ua[row0 + c];
+  }
+  if ((L.cc & 3) == 0 && !stance) s.uv[row0] = s.uv[row0 + 1] = s.uv[row0 + 2] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)s.uv[i];   // src/mpc.py:267-268
+  if (Xg) {                                                          // src/mpc.py:265-266
     struct_grad<SmemF<TV>, TV, N>(s, tid);
     for (int i = tid; i < (N + 1) * 13; i += NT) {
       const int k = i / 13, c = i % 13;
@@ -602,12 +642,47 @@ mpcqp_fast_polish(const DevCfg* __restrict__ cfgp, const double* __restrict__ ct
       Xg[b * (N + 1) * 13 + i] = (TIO)v;
     }
   }
-  STAMP(8);
   if (tid == 0) {
-    statusg[b] = status;
-    itersg[b] += 1000 * psteps;
-    if (resg) { resg[2 * b] = res_p; resg[2 * b + 1] = res_d; }
+    statusg[b] = ok ? MPCQP_STATUS_SOLVED_POLISHED : MPCQP_STATUS_MAX_ITER;
+    itersg[b] = s.iters + 1000 * s.psteps;
+    if (resg) { resg[2 * b] = s.kkt[1]; resg[2 * b + 1] = fmaxf(s.kkt[2], s.kkt[0]); }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------ the kernel
+template <typename TV, typename TIO>
+__global__ void __launch_bounds__(FG::NT, MPCQP_FAST_WPE)
+mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const TIO* __restrict__ x0g,
+                 const TIO* __restrict__ rg, const uint8_t* __restrict__ cg, const TIO* __restrict__ xdg,
+                 const TIO* __restrict__ mug, TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __restrict__ statusg,
+                 int* __restrict__ itersg, float* __restrict__ resg) {
+  constexpr int N = FG::N, n = FG::n, NT = FG::NT;
+  const size_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (ph_setup<TV, TIO>(cfgp, ctab, x0g, rg, cg, xdg, mug, b)) {   // non-finite input -> zero outputs, status -1
+    for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
+    if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (N + 1) * 13 + i] = (TIO)0;
+    if (tid == 0) {
+      statusg[b] = MPCQP_STATUS_NONFINITE;
+      itersg[b] = 0;
+      if (resg) { resg[2 * b] = 0.f; resg[2 * b + 1] = 0.f; }
+    }
+    return;
+  }
+  const int max_iter = cfgp->max_iter, polish_max = cfgp->polish_max;
+  int ok = 0;
+  for (int round = 0;; ++round) {
+    ph_admm<TV>(cfgp, round == 0 ? 1 : 0);
+    SmemF<TV>& s = lds<TV>();
+    const int budget = (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
+    for (int ps = 0; ps < budget && !ok; ++ps) ok = ph_polish_step<TV>();
+    if (ok || s.iters >= max_iter) break;
+    // not solved: OSQP's rho adaptation from the residuals of the last ADMM iterate, then another block
+    const float ratio = ph_ratio<TV>();
+    if (tid == 0 && isfinite(ratio) && (ratio > 2.f || ratio < 0.5f)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
+    __syncthreads();
+  }
+  ph_output<TV, TIO>(ug, Xg, statusg, itersg, resg, b, ok);
 }
 
 }  // namespace

@@ -36,8 +36,6 @@ struct mpcqp_engine {
   DevCfg dev;
   double* ctab = nullptr;   // [2][N][N] coefficient tables on the device
   DevCfg* dcfg = nullptr;   // device copy of `dev`
-  float* ws = nullptr;      // fast path: per-QP ADMM state between the ADMM and polish kernels
-  int64_t ws_cap = 0;       // QPs the workspace holds
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   char err[512];
@@ -63,26 +61,18 @@ hipError_t launch(const mpcqp_engine* e, int64_t B, const void* x0, const void* 
   return hipGetLastError();
 }
 
-// Fast path (mpcqp_fast.h): R = ceil(max_iter / check_every) rounds of {ADMM kernel, polish kernel}; solved QPs exit
-// at the first instruction of the later rounds.
+// Fast path (mpcqp_fast.h): one launch, one QP per workgroup, phases as separately register-allocated device functions.
 template <typename TIO>
 hipError_t launch_fast(const mpcqp_engine* e, int64_t B, const void* x0, const void* r, const uint8_t* c, const void* xd,
                        const void* mu, void* u, void* X, int32_t* st, int32_t* it, float* res, hipStream_t s) {
-  const int rounds = (e->cfg.max_iter + e->cfg.check_every - 1) / e->cfg.check_every;
-  for (int k = 0; k < rounds; ++k) {
-    hipLaunchKernelGGL((mpcqp_fast_admm<TIO>), dim3((unsigned)B), dim3(FG::NT), 0, s, e->dcfg, e->ctab, (const TIO*)x0,
-                       (const TIO*)r, c, (const TIO*)xd, (const TIO*)mu, (TIO*)u, (TIO*)X, st, it, res, e->ws, k == 0 ? 1 : 0);
-    const int last = k == rounds - 1 ? 1 : 0;
-    if (e->cfg.precision == MPCQP_PREC_MIXED)
-      hipLaunchKernelGGL((mpcqp_fast_polish<double, TIO>), dim3((unsigned)B), dim3(FG::NT), 0, s, e->dcfg, e->ctab,
-                         (const TIO*)x0, (const TIO*)r, c, (const TIO*)xd, (const TIO*)mu, (TIO*)u, (TIO*)X, st, it, res, e->ws, last);
-    else
-      hipLaunchKernelGGL((mpcqp_fast_polish<float, TIO>), dim3((unsigned)B), dim3(FG::NT), 0, s, e->dcfg, e->ctab,
-                         (const TIO*)x0, (const TIO*)r, c, (const TIO*)xd, (const TIO*)mu, (TIO*)u, (TIO*)X, st, it, res, e->ws, last);
-    const hipError_t he = hipGetLastError();
-    if (he != hipSuccess) return he;
-  }
-  return hipSuccess;
+  const dim3 grid((unsigned)B);
+  if (e->cfg.precision == MPCQP_PREC_MIXED)
+    hipLaunchKernelGGL((mpcqp_fast_solve<double, TIO>), grid, dim3(FG::NT), 0, s, e->dcfg, e->ctab, (const TIO*)x0,
+                       (const TIO*)r, c, (const TIO*)xd, (const TIO*)mu, (TIO*)u, (TIO*)X, st, it, res);
+  else
+    hipLaunchKernelGGL((mpcqp_fast_solve<float, TIO>), grid, dim3(FG::NT), 0, s, e->dcfg, e->ctab, (const TIO*)x0,
+                       (const TIO*)r, c, (const TIO*)xd, (const TIO*)mu, (TIO*)u, (TIO*)X, st, it, res);
+  return hipGetLastError();
 }
 
 template <typename TIO, int N>
@@ -201,7 +191,6 @@ int mpcqp_destroy(mpcqp_handle h) {
   if (!h) return MPCQP_OK;
   if (h->ctab) (void)hipFree(h->ctab);
   if (h->dcfg) (void)hipFree(h->dcfg);
-  if (h->ws) (void)hipFree(h->ws);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   delete h;
@@ -220,13 +209,6 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
   hipError_t he = hipSuccess;
   const bool fast = h->cfg.N == 10 && h->cfg.precision != MPCQP_PREC_F64 && (h->cfg.flags & MPCQP_FLAG_POLISH) &&
                     !(h->cfg.flags & MPCQP_FLAG_GENERAL_KERNEL) && h->cfg.alpha > 0.0;
-  if (B > 0 && fast && B > h->ws_cap) {   // first call at this batch size: (re)allocate the workspace, before the timed events
-    if (h->ws) (void)hipFree(h->ws);
-    h->ws = nullptr; h->ws_cap = 0;
-    he = hipMalloc((void**)&h->ws, sizeof(float) * (size_t)B * FG::WS);
-    if (he != hipSuccess) return fail(h, MPCQP_ENOMEM, "workspace hipMalloc", he);
-    h->ws_cap = B;
-  }
   he = hipEventRecord(h->ev0, st);
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
   if (B > 0 && fast) {
