@@ -92,6 +92,13 @@ struct Lane {   // who am I inside the workgroup
 
 __device__ __forceinline__ int fpidx(int i) { return (i / FG::CW) * FG::S + i % FG::CW; }
 
+// The register tile is declared as 6 x 8 packed pairs so that the compiler keeps each pair in an aligned register pair
+// and the rank-1 updates / mat-vecs map 1:1 onto v_pk_fma_f32 (with a plain float[6][16] it shuffled ~45 moves per pivot).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef f2 Tile[6][8];
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 t = {a, b}; return t; }   // NB: (f2)(a, b) would be a cast of a comma expression
+__device__ __forceinline__ f2 splat2(float v) { return mk2(v, v); }
+
 // Load the operator tuple, build the per-variable response vectors and the linear term g.  Returns the uniform
 // "non-finite input" flag.  Ends with a barrier.
 template <typename TV, typename TIO>
@@ -153,7 +160,7 @@ __device__ __forceinline__ int fast_setup(SmemF<TV>& s, const DevCfg& cfg, const
 
 // Register tile M[6g..6g+5][15c..15c+14] = 2 (c1 P.P' + c0 Q.Q') + diag, from s.pq / s.dg (two passes of three rows).
 template <typename TV>
-__device__ __forceinline__ void fast_build(float (&tile)[6][16], const SmemF<TV>& s, int grp, int cc) {
+__device__ __forceinline__ void fast_build(Tile& tile, const SmemF<TV>& s, int grp, int cc) {
   constexpr int N = FG::N;
   const int col0 = cc * FG::CW;
 #pragma unroll
@@ -168,7 +175,7 @@ __device__ __forceinline__ void fast_build(float (&tile)[6][16], const SmemF<TV>
     }
 #pragma unroll
     for (int c = 0; c < FG::CW; ++c) {
-      asm volatile("" ::: "memory");  // keep the column loads of different columns from piling up in registers
+      if (c % 3 == 0) asm volatile("" ::: "memory");  // at most three columns' loads in flight: bounds the live registers
       const int ic = col0 + c, jc = ic / 12;
       const float k1 = 2.f * s.c1[stage * N + jc], k0 = 2.f * s.c0[stage * N + jc];
       float pc[12];
@@ -182,18 +189,18 @@ __device__ __forceinline__ void fast_build(float (&tile)[6][16], const SmemF<TV>
         for (int q = 0; q < 6; ++q) { dp += Pr[r3][q] * pc[q]; dq += Pr[r3][6 + q] * pc[6 + q]; }
         float v = k1 * dp + k0 * dq;
         if (ic == r0 + r3) v += s.dg[ic];
-        tile[3 * h + r3][c] = v;
+        if (c % 2 == 0) tile[3 * h + r3][c / 2].x = v; else tile[3 * h + r3][c / 2].y = v;
       }
     }
   }
 #pragma unroll
-  for (int r = 0; r < 6; ++r) tile[r][15] = 0.f;
+  for (int r = 0; r < 6; ++r) tile[r][7].y = 0.f;
 }
 
 // In-register symmetric sweep over the enabled variables: tile <- -M^{-1} (Gauss-Jordan without pivoting, SPD).
 // One LDS broadcast of the pivot row and one barrier per pivot; disabled variables (identity rows) are skipped.
 template <typename TV>
-__device__ __forceinline__ void fast_sweep(float (&tile)[6][16], SmemF<TV>& s, int grp, int cc, int rbA, int rbB) {
+__device__ __forceinline__ void fast_sweep(Tile& tile, SmemF<TV>& s, int grp, int cc, int rbA, int rbB) {
   constexpr int S = FG::S, VP = FG::VP;
   int step = 0;
   for (int kc2 = 0; kc2 < 4; ++kc2) {
@@ -212,30 +219,34 @@ __device__ __forceinline__ void fast_sweep(float (&tile)[6][16], SmemF<TV>& s, i
         if (grp == og) {
           float4* w4 = reinterpret_cast<float4*>(vb + cc * S);
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) w4[q4] = make_float4(tile[rr][4 * q4], tile[rr][4 * q4 + 1], tile[rr][4 * q4 + 2], tile[rr][4 * q4 + 3]);
+          for (int q4 = 0; q4 < 4; ++q4) w4[q4] = make_float4(tile[rr][2 * q4].x, tile[rr][2 * q4].y, tile[rr][2 * q4 + 1].x, tile[rr][2 * q4 + 1].y);
         }
         __syncthreads();
         const float p = __builtin_amdgcn_rcpf(vb[kc * S + c]);
-        float vr[6], vc[16];
+        float vr[6];
+        f2 vc[8];
 #pragma unroll
         for (int r3 = 0; r3 < 3; ++r3) { vr[r3] = vb[rbA + r3] * p; vr[3 + r3] = vb[rbB + r3] * p; }
         {
           const float4* r4 = reinterpret_cast<const float4*>(vb + cc * S);
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) { const float4 v = r4[q4]; vc[4 * q4] = v.x; vc[4 * q4 + 1] = v.y; vc[4 * q4 + 2] = v.z; vc[4 * q4 + 3] = v.w; }
+          for (int q4 = 0; q4 < 4; ++q4) { const float4 v = r4[q4]; vc[2 * q4] = mk2(v.x, v.y); vc[2 * q4 + 1] = mk2(v.z, v.w); }
         }
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 6; ++r) {
+          const f2 m = splat2(-vr[r]);
 #pragma unroll
-          for (int c2 = 0; c2 < 16; ++c2) tile[r][c2] -= vr[r] * vc[c2];
+          for (int j = 0; j < 8; ++j) tile[r][j] = __builtin_elementwise_fma(m, vc[j], tile[r][j]);
+        }
         if (grp == og) {
+          const f2 p2 = splat2(p);
 #pragma unroll
-          for (int c2 = 0; c2 < 16; ++c2) tile[rr][c2] = vc[c2] * p;
+          for (int j = 0; j < 8; ++j) tile[rr][j] = vc[j] * p2;
         }
         if (cc == kc) {
 #pragma unroll
-          for (int r = 0; r < 6; ++r) tile[r][c] = vr[r];
-          if (grp == og) tile[rr][c] = -p;
+          for (int r = 0; r < 6; ++r) { if (c % 2 == 0) tile[r][c / 2].x = vr[r]; else tile[r][c / 2].y = vr[r]; }
+          if (grp == og) { if (c % 2 == 0) tile[rr][c / 2].x = -p; else tile[rr][c / 2].y = -p; }
         }
         ++step;
       }
@@ -244,20 +255,23 @@ __device__ __forceinline__ void fast_sweep(float (&tile)[6][16], SmemF<TV>& s, i
 }
 
 // out[r] = -(tile row r) . x, summed over the 8 lanes of the group (x in the padded LDS layout).
-__device__ __forceinline__ void fast_matvec(const float (&tile)[6][16], const float* __restrict__ x, int cc, float (&out)[6]) {
-  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void fast_matvec(const Tile& tile, const float* __restrict__ x, int cc, float (&out)[6]) {
+  f2 acc[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) acc[r] = mk2(0.f, 0.f);
   const float4* r4 = reinterpret_cast<const float4*>(x + cc * FG::S);
 #pragma unroll
   for (int q4 = 0; q4 < 4; ++q4) {
     const float4 v = r4[q4];
-    const float xv[4] = {v.x, v.y, v.z, v.w};
+    const f2 xa = mk2(v.x, v.y), xb = mk2(v.z, v.w);
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int r = 0; r < 6; ++r) acc[r] += tile[r][4 * q4 + e] * xv[e];
+    for (int r = 0; r < 6; ++r) {
+      acc[r] = __builtin_elementwise_fma(tile[r][2 * q4], xa, acc[r]);
+      acc[r] = __builtin_elementwise_fma(tile[r][2 * q4 + 1], xb, acc[r]);
+    }
   }
 #pragma unroll
-  for (int r = 0; r < 6; ++r) out[r] = -group8_sum(acc[r]);
+  for (int r = 0; r < 6; ++r) out[r] = -group8_sum(acc[r].x + acc[r].y);
 }
 
 // Writes the 12-vectors / diagonal / enable mask of one leg-stage's three variables (lanes a = 0..2 of the leg's
@@ -298,7 +312,7 @@ __device__ __forceinline__ void fast_describe(SmemF<TV>& s, int myleg, int a, bo
 // leg-stage (src/mpc.py:138-173).  State (u, z, y) in registers, right-hand sides double-buffered in LDS, one barrier
 // per iteration.  tile = -M^{-1}.
 template <typename TV>
-__device__ __forceinline__ void fast_admm_iters(const float (&tile)[6][16], SmemF<TV>& s, const int iters, const float rho,
+__device__ __forceinline__ void fast_admm_iters(const Tile& tile, SmemF<TV>& s, const int iters, const float rho,
                                                 const float sigma, const float relax, const float mu, const bool stance,
                                                 const float fmin, const float fmax, const float (&g3)[3], float (&u3)[3],
                                                 float (&z5)[5], float (&y5)[5], const int cc, const bool second, const int rbM) {
@@ -424,7 +438,7 @@ MPCQP_PHASE void ph_admm(const DevCfg* __restrict__ cfgp, const int adapt) {
   int it = 0, seg_end = (adapt && ADAPT_AT < K) ? ADAPT_AT : K;
   bool need_build = true;
   int hard = 0;
-  float tile[6][16];
+  Tile tile;
   STAMP_INIT
   for (;;) {
     if (need_build) {
@@ -484,7 +498,7 @@ MPCQP_PHASE int ph_polish_step() {
   const float dtol = (sizeof(TV) == 8) ? (1e-5f + 1e-9f * gmaxf) : (2e-5f * fmaxf(1.f, gmaxf));
   bool ok = false;
   float stat = INFINITY, viol[3] = {0.f, 0.f, 0.f};
-  float tile[6][16];
+  Tile tile;
   STAMP_INIT
   {
   // primal-dual active-set rule on (pu, py): rows 0 fz | 1 fx - mu fz <= 0 | 2 fx + mu fz >= 0 | 3,4 same for fy
