@@ -154,8 +154,8 @@ def main():
                        "solved_fraction": solved, "admm_iters_mean": k_mean, "polish_steps_mean": float((iters // 1000).mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                         "kernel": "one solve_batch = mpcqp_fast_admm<float> + mpcqp_fast_polish<double,float>, x rounds "
-                                   "(rocprofv3 kernel stats: sum of TotalDurationNs of both / steps)",
+                         "kernel": "mpcqp_fast_solve<double,float> (one launch per solve_batch)" if args.precision == "mixed"
+                         else "mpcqp_fast_solve<float,float>" if args.precision == "f32" else "mpcqp_solve_kernel<double,double,float,10>",
                          "kernel_ms": kernel_ms, "kernel_ms_last_launch": last_ms,
                          "algorithmic_flops_per_qp": flops,
                          "hbm": {"achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS,
