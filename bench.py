@@ -89,24 +89,35 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    device_index = local_rank % ndev        # one rank per GPU on a real node; wraps only in single-GPU rehearsals
+    torch.cuda.set_device(device_index)
     dist = None
+    backend = os.environ.get("MPCQP_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" for 1-GPU rehearsals
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
+    sync_device = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
 
     N, delta, B = 10, 0.03, args.batch
     gaits, mus = ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0)
     batch = mpcqp.synth.make_batch(B, N, delta, 20250809 + rank, gaits, mus)      # this rank's shard
-    solver = mpcqp.MPCBatch(N=N, delta=delta, device=local_rank, io_dtype="f32", precision=args.precision)
+    solver = mpcqp.MPCBatch(N=N, delta=delta, device=device_index, io_dtype="f32", precision=args.precision)
     dev = solver.upload(batch)
-    gathered = torch.empty((world * B, 12), dtype=torch.float32, device=solver.device) if args.allgather and world > 1 else None
+    gathered = (torch.empty((world * B, 12), dtype=torch.float32, device=solver.device)
+                if args.allgather and world > 1 and backend == "nccl" else None)
 
     def step():
         out = solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], want_X=False)
         if gathered is not None:
-            dist.all_gather_into_tensor(gathered, out["u"][:, 0, :].contiguous())
+            dist.all_gather_into_tensor(gathered, out["u"][:, 0, :].contiguous())   # RCCL over xGMI
         return out
 
     for _ in range(args.warmup):
@@ -128,13 +139,18 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps       # average launch duration over the timed region
     last_ms = solver.last_kernel_ms()                    # engine's own event pair around the last launch
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=solver.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=sync_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)     # the job is as slow as its slowest rank
+        dt, kernel_ms = float(t[0].item()), float(t[1].item())
+        agg = torch.tensor([float(((out["status"] == 1) | (out["status"] == 2)).sum().item())], dtype=torch.float64, device=sync_device)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        solved_all = float(agg.item()) / (world * B)
 
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
     solved = float(((status == 1) | (status == 2)).mean())
+    if dist:
+        solved = solved_all
     k_mean = float((iters % 1000).mean())
     if rank == 0:
         value = world * B * args.steps / dt
