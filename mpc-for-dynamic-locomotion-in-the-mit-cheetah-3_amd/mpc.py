@@ -91,9 +91,20 @@ class MPC:
         self._builder = MPCProblemBuilder(initial, footstep_planner, params)
         self.trajectory_generator = self._builder.trajectory_generator
         self.m = 8.885                                    # src/mpc.py:71 (engine default; kept as an attribute)
-        self._solver = MPCBatch(N=self.N, delta=self.delta, device=device, io_dtype="f64", precision=precision,
-                                **engine_overrides)
+        self._solver = self._make_solver(device, precision, engine_overrides)
         self.status = None
+
+    def _make_solver(self, device, precision, engine_overrides):
+        """The HIP engine.  (tests/ override this hook to drive the same surface with the CPU checker.)"""
+        return MPCBatch(N=self.N, delta=self.delta, device=device, io_dtype="f64", precision=precision, **engine_overrides)
+
+    def _solve_one(self, x0, r, contact, xdes):
+        import torch
+        dev = self._solver.upload({"x0": x0[None], "r": r[None], "contact": contact[None], "xdes": xdes[None],
+                                   "mu": np.array([float(self.mu)])})
+        out = self._solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], want_X=True)
+        torch.cuda.synchronize(self._solver.device)
+        return out["u"][0].cpu().numpy(), out["X"][0].cpu().numpy(), int(out["status"][0].item())
 
     # the reference keeps these on the instance and mutates them every tick
     @property
@@ -108,17 +119,12 @@ class MPC:
         return self._builder.update_r_num(time, leg_name, next_com)
 
     def solve(self, t, logger):
-        import torch
         current_state = self.lite3.retrieve_state()
         x0, r, contact, xdes, v_ref, omega = self._builder.build(t, current_state)
         self.x = x0.reshape(13, 1)
-        dev = self._solver.upload({"x0": x0[None], "r": r[None], "contact": contact[None], "xdes": xdes[None],
-                                   "mu": np.array([float(self.mu)])})
-        out = self._solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], want_X=True)
-        torch.cuda.synchronize(self._solver.device)
-        U = out["u"][0].cpu().numpy().T.copy()            # 12 x N, like sol.value(U)
-        X = out["X"][0].cpu().numpy().T.copy()            # 13 x (N+1)
-        self.status = int(out["status"][0].item())
+        u, Xs, self.status = self._solve_one(x0, r, contact, xdes)
+        U = u.T.copy()                                    # 12 x N, like sol.value(U)
+        X = Xs.T.copy()                                   # 13 x (N+1)
         self._builder.advance_reference(v_ref, omega)
         self.x_log = X[:-1, :]                            # src/mpc.py:265-268
         self.x_plot = X[3:6, :]

@@ -1,0 +1,67 @@
+"""Config 1 of BASELINE.json (plumbing, no GPU): a single Lite3 trotting, horizon 10, dt 0.03, 300 ticks of the whole
+caller chain customPreStep -> ground_controller -> MPC.solve(t, logger) -> update_r_num / planner / logger hooks, with the
+DART world replaced by the kinematic single-rigid-body stand-in.  The engine has no CPU path, so here the solve hook of
+`MPC` is overridden IN THE TEST to call the CPU checker (tests may do that; the product never does)."""
+import numpy as np
+
+import mpcqp
+from conftest import ORACLE_SO
+from mpcqp import lite3_model
+from mpcqp.controller import Lite3Controller
+from mpcqp.mpc import MPC
+
+
+class OracleMPC(MPC):
+    def _make_solver(self, device, precision, engine_overrides):
+        lib = mpcqp.Library(ORACLE_SO)
+        return mpcqp.Engine(lib, lib.default_config(N=self.N, delta=self.delta, max_iter=4000, **engine_overrides))
+
+    def _solve_one(self, x0, r, contact, xdes):
+        out = self._solver.solve_batch_host(x0[None], r[None], contact[None], xdes[None], np.array([float(self.mu)]))
+        return out["u"][0], out["X"][0], int(out["status"][0])
+
+
+def test_leg_jacobian_matches_finite_differences():
+    rng = np.random.default_rng(0)
+    for leg in range(4):
+        q = np.array([0.1, -1.0, 1.6]) + rng.normal(0, 0.2, 3)
+        p, J = lite3_model.leg_fk_jac(leg, q)
+        Jn = np.stack([(lite3_model.leg_fk_jac(leg, q + 1e-6 * np.eye(3)[i])[0] - p) / 1e-6 for i in range(3)], axis=1)
+        assert np.abs(J - Jn).max() < 1e-5
+        assert np.abs(lite3_model.leg_fk_jac(leg, lite3_model.leg_ik(leg, p, q0=q + 0.05))[0] - p).max() < 1e-9
+    # the reference's spawn pose (HipY -60 deg, Knee 90 deg, src/main.py:65-68) puts the feet under the hips
+    p, _ = lite3_model.leg_fk_jac(0, np.radians([0.0, -60.0, 90.0]))
+    assert abs(p[1] - (0.062 + 0.0985)) < 1e-12 and -0.32 < p[2] < -0.2
+
+
+def test_config1_closed_loop_plumbing(oracle_lib):
+    ctl = Lite3Controller(OracleMPC)
+    T = 300
+    contact = []
+    for t in range(T):
+        contact.append(ctl.footstep_planner.get_phase_at_time(t))     # before the tick: the swing query below mutates feet_id
+        tau = ctl.customPreStep()
+        assert set(tau) == set(mpcqp.footstep_planner.LEGS) and all(np.all(np.isfinite(v)) for v in tau.values())
+        assert ctl.mpc.status in (1, 2)
+    log = ctl.logger.log
+    assert len(log["time array"]) == T and len(log["TRACKING PERFORMANCE"]["actual"]) == T
+    assert all(len(log["FORCES"][l]["z"]) == T for l in log["FORCES"])
+    assert all(len(log["FEET POS"][l]["des"]) == T for l in log["FEET POS"])
+    assert [p["time step"] for p in log["MPC PREDICTIONS"]] == [0, 80] and log["mpc_freq"] > 0
+    fz = np.array([log["FORCES"][l]["z"] for l in mpcqp.footstep_planner.LEGS])        # [4,T]
+    # trot: diagonal pairs alternate; a swing leg carries exactly zero force, stance legs respect 3 <= fz <= 100
+    contact = np.array(contact).T
+    assert np.all(fz[contact == 0] == 0) and np.all(fz[contact == 1] >= 3 - 1e-6) and np.all(fz <= 100 + 1e-6)
+    # the body is carried: mean total vertical force ~ m g, height and forward speed tracked
+    assert abs(fz.sum(axis=0).mean() - 8.885 * 9.81) < 0.15 * 8.885 * 9.81
+    x = ctl.lite3.x
+    assert abs(x[5] - 0.285) < 0.03 and 0.05 < x[9] < 0.5 and np.abs(x[0:2]).max() < 0.2
+    # reference roll-forward of the targets (src/mpc.py:261-262)
+    assert abs(ctl.mpc.com_pos_start[0] - T * 0.03 * 0.18) < 1e-9
+    # log dump / reload without pickle
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "log.npz")
+        ctl.logger.save_log(f)
+        back = ctl.logger.load_log(f)
+        assert back["FORCES/FL_FOOT/z"].shape == (T,) and "MPC PREDICTIONS/1/predicted_state" in back
