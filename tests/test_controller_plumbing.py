@@ -59,7 +59,8 @@ def test_config1_closed_loop_plumbing(oracle_lib):
     assert abs(fz[:, :15].sum(axis=0).mean() - 8.885 * 9.81) < 0.15 * 8.885 * 9.81
     assert np.all(np.isfinite(ctl.lite3.x))
     # reference roll-forward of the targets (src/mpc.py:261-262)
-    assert abs(ctl.mpc.com_pos_start[0] - T * 0.03 * 0.18) < 1e-9
+    # ... which stops on the last plan step (src/mpc.py:181-183): 19 moving steps of 15 ticks
+    assert abs(ctl.mpc.com_pos_start[0] - 19 * 15 * 0.03 * 0.18) < 1e-9
     # log dump / reload without pickle
     import os, tempfile
     with tempfile.TemporaryDirectory() as d:
