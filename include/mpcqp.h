@@ -118,6 +118,25 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
                       const void* xdes, const void* mu, void* u_out, void* X_out, int32_t* status,
                       int32_t* iters, float* res, void* stream);
 
+/*
+ * Same solve, but from compact per-robot gait descriptors: the engine expands them ON THE DEVICE into contact / r / xdes
+ * exactly as MPC.solve does on the host every tick (src/mpc.py:178-254) with the planner queries of
+ * src/footstep_planner.py:226-246 -- about 100 B per QP cross the boundary instead of 1.1 KB, and no host loop runs.
+ *   x0        T  [B,13]     as above
+ *   ref       T  [B,10]     roll0, pitch0 (initial['roll'/'pitch']), yaw_start, com_pos_start[3], v_com_ref[3], theta_dot
+ *                           (src/mpc.py:36-38,178-183,202-214)
+ *   feet0     T  [B,4,3]    measured foot positions, stage 0 (src/mpc.py:223-226)
+ *   footholds T  [B,2,4,3]  plan[step]['pos'] of the current and of the next step (src/mpc.py:306-318)
+ *   gait      i32[B,4]      ticks elapsed in the current step, ss_duration, ds_duration, reserved (0)
+ *   feet_id   u8 [B,2,4]    plan[step]['feet_id'] of the current and of the next step (1 = stance during single support)
+ * Stage k uses step 0 while t_in_step + k < ss + ds, else step 1; N must not exceed ss + ds so that the horizon spans at
+ * most two steps.  Outputs as mpcqp_solve_batch.  Product library: fast path only (N = 10, MIXED/F32, polish, alpha > 0);
+ * otherwise MPCQP_EINVAL.  The oracle library does not export this entry (tests expand the descriptors on the host).
+ */
+int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void* ref, const void* feet0,
+                           const void* footholds, const int32_t* gait, const uint8_t* feet_id, const void* mu,
+                           void* u_out, void* X_out, int32_t* status, int32_t* iters, float* res, void* stream);
+
 /* Duration in milliseconds of the most recent solve_batch's kernel(s), measured with HIP events recorded on
  * `stream` around the launch; blocks until that work has finished.  Oracle: wall time of the call. */
 int mpcqp_last_kernel_ms(mpcqp_handle h, float* ms);

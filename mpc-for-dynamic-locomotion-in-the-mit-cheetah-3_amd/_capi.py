@@ -25,7 +25,7 @@ FLAG_POLISH, FLAG_WARM_START, FLAG_GENERAL_KERNEL = 1, 2, 4
 
 EXPORTED_SYMBOLS = (
     "mpcqp_version", "mpcqp_default_config", "mpcqp_create", "mpcqp_destroy", "mpcqp_solve_batch",
-    "mpcqp_last_kernel_ms", "mpcqp_last_error",
+    "mpcqp_solve_batch_gait", "mpcqp_last_kernel_ms", "mpcqp_last_error",
 )
 
 
@@ -70,6 +70,8 @@ class Library:
         L.mpcqp_destroy.restype = c_int32
         L.mpcqp_solve_batch.argtypes = [c_void_p, c_int64] + [c_void_p] * 11
         L.mpcqp_solve_batch.restype = c_int32
+        L.mpcqp_solve_batch_gait.argtypes = [c_void_p, c_int64] + [c_void_p] * 13
+        L.mpcqp_solve_batch_gait.restype = c_int32
         L.mpcqp_last_kernel_ms.argtypes = [c_void_p, ctypes.POINTER(c_float)]
         L.mpcqp_last_kernel_ms.restype = c_int32
         L.mpcqp_last_error.argtypes = [c_void_p]
@@ -127,6 +129,13 @@ class Engine:
         if rc != 0:
             raise MpcQpError(f"mpcqp_solve_batch failed with code {rc}: {self.last_error()}")
 
+    def solve_batch_gait_ptr(self, B, x0, ref, feet0, footholds, gait, feet_id, mu, u_out, X_out, status, iters, res, stream=0):
+        """Raw call of the gait entry point (addresses; device memory for the product library)."""
+        rc = self.library.lib.mpcqp_solve_batch_gait(self._h, int(B), x0, ref, feet0, footholds, gait, feet_id, mu, u_out,
+                                                     X_out or None, status, iters, res or None, stream or None)
+        if rc != 0:
+            raise MpcQpError(f"mpcqp_solve_batch_gait failed with code {rc}: {self.last_error()}")
+
     def last_kernel_ms(self) -> float:
         ms = c_float()
         rc = self.library.lib.mpcqp_last_kernel_ms(self._h, ctypes.byref(ms))
@@ -150,6 +159,21 @@ class Engine:
         self.solve_batch_ptr(B, x0.ctypes.data, r.ctypes.data, contact.ctypes.data, xdes.ctypes.data, mu.ctypes.data,
                              u.ctypes.data, X.ctypes.data if want_X else None, status.ctypes.data, iters.ctypes.data,
                              res.ctypes.data)
+        return {"u": u, "X": X, "status": status, "iters": iters, "res": res}
+
+
+    def solve_batch_gait_host(self, g, want_X=True):
+        """Host-pointer convenience for the gait entry point; `g` is a dict as produced by synth.make_gait_batch."""
+        N = self.cfg.N
+        ft = np.float64 if self.cfg.dtype == DTYPE_F64 else np.float32
+        a = {k: np.ascontiguousarray(g[k], dtype=ft) for k in ("x0", "ref", "feet0", "footholds", "mu")}
+        gait = np.ascontiguousarray(g["gait"], dtype=np.int32); fid = np.ascontiguousarray(g["feet_id"], dtype=np.uint8)
+        B = a["x0"].shape[0]
+        u = np.zeros((B, N, 12), ft); X = np.zeros((B, N + 1, 13), ft) if want_X else None
+        status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); res = np.zeros((B, 2), np.float32)
+        self.solve_batch_gait_ptr(B, a["x0"].ctypes.data, a["ref"].ctypes.data, a["feet0"].ctypes.data, a["footholds"].ctypes.data,
+                                  gait.ctypes.data, fid.ctypes.data, a["mu"].ctypes.data, u.ctypes.data,
+                                  X.ctypes.data if want_X else None, status.ctypes.data, iters.ctypes.data, res.ctypes.data)
         return {"u": u, "X": X, "status": status, "iters": iters, "res": res}
 
 

@@ -99,25 +99,78 @@ typedef f2 Tile[6][8];
 __device__ __forceinline__ f2 mk2(float a, float b) { f2 t = {a, b}; return t; }   // NB: (f2)(a, b) would be a cast of a comma expression
 __device__ __forceinline__ f2 splat2(float v) { return mk2(v, v); }
 
-// Load the operator tuple, build the per-variable response vectors and the linear term g.  Returns the uniform
-// "non-finite input" flag.  Ends with a barrier.
+// Inputs of one solve: either the expanded operator tuple (x0, r, contact, xdes, mu) or, for the gait entry point, compact
+// descriptors that are expanded into the same LDS arrays on the device.
+template <typename TIO>
+struct FastIn {
+  const TIO* x0; const TIO* r; const uint8_t* contact; const TIO* xdes; const TIO* mu;             // tuple form
+  const TIO* ref; const TIO* feet0; const TIO* footholds; const int32_t* gait; const uint8_t* feet_id;   // gait form
+};
+
+// Tuple form (src/mpc.py:242-255).  Returns the per-thread "non-finite input" flag.
 template <typename TV, typename TIO>
-__device__ __forceinline__ int fast_setup(SmemF<TV>& s, const DevCfg& cfg, const double* __restrict__ ctab,
-                                          const TIO* __restrict__ x0g, const TIO* __restrict__ rg,
-                                          const uint8_t* __restrict__ cg, const TIO* __restrict__ xdg,
-                                          const TIO* __restrict__ mug, size_t b, int tid) {
-  constexpr int N = FG::N, n = FG::n, NT = FG::NT;
+__device__ __forceinline__ int fast_load_tuple(SmemF<TV>& s, const FastIn<TIO>& in, size_t b, int tid) {
+  constexpr int N = FG::N, NT = FG::NT;
   int bad = 0;
-  for (int i = tid; i < 13; i += NT) { const TV v = (TV)x0g[b * 13 + i]; s.x0[i] = v; bad |= !isfinite(v); }
-  for (int i = tid; i < (N + 1) * 13; i += NT) { const TV v = (TV)xdg[b * (N + 1) * 13 + i]; s.xd[i] = v; bad |= !isfinite(v); }
-  for (int i = tid; i < N * 12; i += NT) { const TV v = (TV)rg[b * N * 12 + i]; s.rr[i] = v; bad |= !isfinite(v); }
-  for (int i = tid; i < N * 4; i += NT) s.ct[i] = cg[b * N * 4 + i] ? 1 : 0;
+  for (int i = tid; i < 13; i += NT) { const TV v = (TV)in.x0[b * 13 + i]; s.x0[i] = v; bad |= !isfinite(v); }
+  for (int i = tid; i < (N + 1) * 13; i += NT) { const TV v = (TV)in.xdes[b * (N + 1) * 13 + i]; s.xd[i] = v; bad |= !isfinite(v); }
+  for (int i = tid; i < N * 12; i += NT) { const TV v = (TV)in.r[b * N * 12 + i]; s.rr[i] = v; bad |= !isfinite(v); }
+  for (int i = tid; i < N * 4; i += NT) s.ct[i] = in.contact[b * N * 4 + i] ? 1 : 0;
+  if (tid == 0) { const TV m = (TV)in.mu[b]; s.mu = m; bad |= !isfinite(m); }
+  return bad;
+}
+
+// Gait form: what MPC.solve computes on the host every tick (src/mpc.py:178-254) from the planner queries
+// (src/footstep_planner.py:226-246), done here per QP:
+//   x_des[k]   = [roll0, pitch0, yaw_start + k d w, com_start + k d v, 0, 0, w, v, g]             (src/mpc.py:202-214)
+//   contact[k] = feet_id[step(k)] during that step's first ss ticks, else all stance          (footstep_planner.py:239-246)
+//   r[0]       = measured foot - measured com;  r[k>=1] = planned foothold of step(k) - x_des com(k)   (src/mpc.py:218-239)
+// with step(k) = 0 while t_in_step + k < ss + ds, else 1 (the horizon spans at most two steps; past the second step's
+// end everything is stance, like the clamped end of the plan).  ref = [roll0, pitch0, yaw_start, com_start(3), v(3), w].
+template <typename TV, typename TIO>
+__device__ __forceinline__ int fast_load_gait(SmemF<TV>& s, const FastIn<TIO>& in, const DevCfg& cfg, size_t b, int tid) {
+  constexpr int N = FG::N, NT = FG::NT;
+  int bad = 0;
+  const TV d = (TV)cfg.delta;
+  const int tis = in.gait[b * 4 + 0], ss = in.gait[b * 4 + 1], ds = in.gait[b * 4 + 2];
+  const TIO* ref = in.ref + b * 10;
+  for (int i = tid; i < 13; i += NT) { const TV v = (TV)in.x0[b * 13 + i]; s.x0[i] = v; bad |= !isfinite(v); }
+  for (int i = tid; i < (N + 1) * 13; i += NT) {
+    const int k = i / 13, c = i % 13;
+    TV v;
+    if (c < 2) v = (TV)ref[c];
+    else if (c == 2) v = (TV)ref[2] + (TV)k * d * (TV)ref[9];
+    else if (c < 6) v = (TV)ref[c] + (TV)k * d * (TV)ref[6 + (c - 3)];
+    else if (c < 8) v = (TV)0;
+    else if (c == 8) v = (TV)ref[9];
+    else if (c < 12) v = (TV)ref[6 + (c - 9)];
+    else v = (TV)in.x0[b * 13 + 12];
+    s.xd[i] = v;
+    bad |= !isfinite(v);
+  }
+  for (int i = tid; i < N * 12; i += NT) {
+    const int k = i / 12, l = (i % 12) / 3, a = i % 3;
+    int tau = tis + k, st = 0;
+    if (tau >= ss + ds) { tau -= ss + ds; st = 1; }
+    TV v;
+    if (k == 0) v = (TV)in.feet0[b * 12 + l * 3 + a] - (TV)in.x0[b * 13 + 3 + a];
+    else v = (TV)in.footholds[b * 24 + st * 12 + l * 3 + a] - ((TV)ref[3 + a] + (TV)k * d * (TV)ref[6 + a]);
+    s.rr[i] = v;
+    bad |= !isfinite(v);
+    if (a == 0) s.ct[k * 4 + l] = (tau < ss) ? (in.feet_id[b * 8 + st * 4 + l] ? 1 : 0) : 1;
+  }
+  if (tid == 0) { const TV m = (TV)in.mu[b]; s.mu = m; bad |= !isfinite(m); }
+  return bad;
+}
+
+// Stage the constants, build the per-variable response vectors and the linear term g.  Returns the uniform
+// "non-finite input" flag.  Ends with a barrier.
+template <typename TV>
+__device__ __forceinline__ int fast_setup(SmemF<TV>& s, const DevCfg& cfg, const double* __restrict__ ctab, int bad, int tid) {
+  constexpr int N = FG::N, n = FG::n, NT = FG::NT;
   for (int i = tid; i < N * N; i += NT) { s.c0[i] = (float)ctab[i]; s.c1[i] = (float)ctab[N * N + i]; }
   for (int i = tid; i < 2 * FG::VP; i += NT) { s.vbuf[i] = 0.f; s.rhs[i] = 0.f; }   // pad slots must stay finite
   if (tid == 0) {
-    const TV m = (TV)mug[b];
-    s.mu = m;
-    bad |= !isfinite(m);
     s.cf.delta = (TV)cfg.delta; s.cf.theta = (TV)cfg.theta; s.cf.alpha = (TV)cfg.alpha; s.cf.inv_m = (TV)cfg.inv_m;
     s.cf.fmin = (TV)cfg.fmin; s.cf.fmax = (TV)cfg.fmax;
   }
@@ -363,13 +416,12 @@ constexpr int HARD_ITER_FACTOR = 3;      // ADMM block length of the QPs that tr
 constexpr int HARD_POLISH_FACTOR = 2;    // ... and their polish-step budget (x polish_max)
 
 // ------------------------------------------------------------------------------------------------------ phases
-template <typename TV, typename TIO>
-MPCQP_PHASE int ph_setup(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const TIO* __restrict__ x0g,
-                         const TIO* __restrict__ rg, const uint8_t* __restrict__ cg, const TIO* __restrict__ xdg,
-                         const TIO* __restrict__ mug, size_t b) {
+template <typename TV, typename TIO, bool GAIT>
+MPCQP_PHASE int ph_setup(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const FastIn<TIO> in, size_t b) {
   SmemF<TV>& s = lds<TV>();
   const int tid = threadIdx.x;
-  if (fast_setup<TV, TIO>(s, *cfgp, ctab, x0g, rg, cg, xdg, mug, b, tid)) return 1;
+  const int bad = GAIT ? fast_load_gait<TV, TIO>(s, in, *cfgp, b, tid) : fast_load_tuple<TV, TIO>(s, in, b, tid);
+  if (fast_setup<TV>(s, *cfgp, ctab, bad, tid)) return 1;
   for (int i = tid; i < FG::n; i += FG::NT) { s.ua[i] = 0.f; s.pu[i] = (TV)0; }
   for (int i = tid; i < FG::NL * 5; i += FG::NT) { s.za[i] = 0.f; s.ya[i] = 0.f; s.py[i] = (TV)0; }
   float q[1] = {tid < FG::n ? fabsf((float)s.gl[tid]) : 0.f};
@@ -664,16 +716,15 @@ MPCQP_PHASE void ph_output(TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __re
 }
 
 // ------------------------------------------------------------------------------------------------------ the kernel
-template <typename TV, typename TIO>
+template <typename TV, typename TIO, bool GAIT>
 __global__ void __launch_bounds__(FG::NT, MPCQP_FAST_WPE)
-mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const TIO* __restrict__ x0g,
-                 const TIO* __restrict__ rg, const uint8_t* __restrict__ cg, const TIO* __restrict__ xdg,
-                 const TIO* __restrict__ mug, TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __restrict__ statusg,
-                 int* __restrict__ itersg, float* __restrict__ resg) {
+mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const FastIn<TIO> in,
+                 TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __restrict__ statusg, int* __restrict__ itersg,
+                 float* __restrict__ resg) {
   constexpr int N = FG::N, n = FG::n, NT = FG::NT;
   const size_t b = blockIdx.x;
   const int tid = threadIdx.x;
-  if (ph_setup<TV, TIO>(cfgp, ctab, x0g, rg, cg, xdg, mug, b)) {   // non-finite input -> zero outputs, status -1
+  if (ph_setup<TV, TIO, GAIT>(cfgp, ctab, in, b)) {   // non-finite input -> zero outputs, status -1
     for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
     if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (N + 1) * 13 + i] = (TIO)0;
     if (tid == 0) {

@@ -62,17 +62,22 @@ hipError_t launch(const mpcqp_engine* e, int64_t B, const void* x0, const void* 
 }
 
 // Fast path (mpcqp_fast.h): one launch, one QP per workgroup, phases as separately register-allocated device functions.
-template <typename TIO>
-hipError_t launch_fast(const mpcqp_engine* e, int64_t B, const void* x0, const void* r, const uint8_t* c, const void* xd,
-                       const void* mu, void* u, void* X, int32_t* st, int32_t* it, float* res, hipStream_t s) {
+template <typename TIO, bool GAIT>
+hipError_t launch_fast(const mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
+                       float* res, hipStream_t s) {
   const dim3 grid((unsigned)B);
   if (e->cfg.precision == MPCQP_PREC_MIXED)
-    hipLaunchKernelGGL((mpcqp_fast_solve<double, TIO>), grid, dim3(FG::NT), 0, s, e->dcfg, e->ctab, (const TIO*)x0,
-                       (const TIO*)r, c, (const TIO*)xd, (const TIO*)mu, (TIO*)u, (TIO*)X, st, it, res);
+    hipLaunchKernelGGL((mpcqp_fast_solve<double, TIO, GAIT>), grid, dim3(FG::NT), 0, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
+                       st, it, res);
   else
-    hipLaunchKernelGGL((mpcqp_fast_solve<float, TIO>), grid, dim3(FG::NT), 0, s, e->dcfg, e->ctab, (const TIO*)x0,
-                       (const TIO*)r, c, (const TIO*)xd, (const TIO*)mu, (TIO*)u, (TIO*)X, st, it, res);
+    hipLaunchKernelGGL((mpcqp_fast_solve<float, TIO, GAIT>), grid, dim3(FG::NT), 0, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
+                       st, it, res);
   return hipGetLastError();
+}
+
+bool fast_path_applies(const mpcqp_engine* h) {
+  return h->cfg.N == 10 && h->cfg.precision != MPCQP_PREC_F64 && (h->cfg.flags & MPCQP_FLAG_POLISH) &&
+         !(h->cfg.flags & MPCQP_FLAG_GENERAL_KERNEL) && h->cfg.alpha > 0.0;
 }
 
 template <typename TIO, int N>
@@ -207,13 +212,19 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
     return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch: null buffer");
   hipStream_t st = (hipStream_t)stream;
   hipError_t he = hipSuccess;
-  const bool fast = h->cfg.N == 10 && h->cfg.precision != MPCQP_PREC_F64 && (h->cfg.flags & MPCQP_FLAG_POLISH) &&
-                    !(h->cfg.flags & MPCQP_FLAG_GENERAL_KERNEL) && h->cfg.alpha > 0.0;
+  const bool fast = fast_path_applies(h);
   he = hipEventRecord(h->ev0, st);
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
   if (B > 0 && fast) {
-    he = h->cfg.dtype == MPCQP_DTYPE_F64 ? launch_fast<double>(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, st)
-                                         : launch_fast<float>(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, st);
+    if (h->cfg.dtype == MPCQP_DTYPE_F64) {
+      const FastIn<double> in = {(const double*)x0, (const double*)r, contact, (const double*)xdes, (const double*)mu,
+                                 nullptr, nullptr, nullptr, nullptr, nullptr};
+      he = launch_fast<double, false>(h, B, in, u_out, X_out, status, iters, res, st);
+    } else {
+      const FastIn<float> in = {(const float*)x0, (const float*)r, contact, (const float*)xdes, (const float*)mu,
+                                nullptr, nullptr, nullptr, nullptr, nullptr};
+      he = launch_fast<float, false>(h, B, in, u_out, X_out, status, iters, res, st);
+    }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
   } else if (B > 0) {
     const bool f64io = h->cfg.dtype == MPCQP_DTYPE_F64;
@@ -223,6 +234,36 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
     else
       he = f64io ? launch_prec<double, 20>(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, st)
                  : launch_prec<float, 20>(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, st);
+    if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
+  }
+  he = hipEventRecord(h->ev1, st);
+  if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
+  h->timed = true;
+  return MPCQP_OK;
+}
+
+int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void* ref, const void* feet0, const void* footholds,
+                           const int32_t* gait, const uint8_t* feet_id, const void* mu, void* u_out, void* X_out,
+                           int32_t* status, int32_t* iters, float* res, void* stream) {
+  if (!h) return MPCQP_EINVAL;
+  if (B < 0 || B > 0x7fffffff) return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: batch size out of range");
+  if (B > 0 && (!x0 || !ref || !feet0 || !footholds || !gait || !feet_id || !mu || !u_out || !status || !iters))
+    return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: null buffer");
+  if (!fast_path_applies(h))
+    return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: needs N = 10, MIXED or F32 precision, polish, alpha > 0");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t he = hipEventRecord(h->ev0, st);
+  if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
+  if (B > 0) {
+    if (h->cfg.dtype == MPCQP_DTYPE_F64) {
+      const FastIn<double> in = {(const double*)x0, nullptr, nullptr, nullptr, (const double*)mu, (const double*)ref,
+                                 (const double*)feet0, (const double*)footholds, gait, feet_id};
+      he = launch_fast<double, true>(h, B, in, u_out, X_out, status, iters, res, st);
+    } else {
+      const FastIn<float> in = {(const float*)x0, nullptr, nullptr, nullptr, (const float*)mu, (const float*)ref,
+                                (const float*)feet0, (const float*)footholds, gait, feet_id};
+      he = launch_fast<float, true>(h, B, in, u_out, X_out, status, iters, res, st);
+    }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
   }
   he = hipEventRecord(h->ev1, st);

@@ -74,5 +74,32 @@ class MPCBatch:
                                     out["iters"].data_ptr(), out["res"].data_ptr(), st.cuda_stream)
         return out
 
+    def upload_gait(self, g):
+        """Host numpy gait descriptors (mpcqp.synth.make_gait_batch layout) -> resident device tensors."""
+        torch = _torch()
+        f = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=self.tdtype).to(self.device).contiguous()
+        return {"x0": f(g["x0"]), "ref": f(g["ref"]), "feet0": f(g["feet0"]), "footholds": f(g["footholds"]), "mu": f(g["mu"]),
+                "gait": torch.as_tensor(np.ascontiguousarray(g["gait"], dtype=np.int32)).to(self.device).contiguous(),
+                "feet_id": torch.as_tensor(np.ascontiguousarray(g["feet_id"], dtype=np.uint8)).to(self.device).contiguous()}
+
+    def solve_batch_gait(self, x0, ref, feet0, footholds, gait, feet_id, mu, want_X=False, stream=None):
+        """Gait entry point: contact masks, stance lever arms and x_des are generated on the device (include/mpcqp.h)."""
+        torch = _torch()
+        N = self.N
+        B = int(x0.shape[0])
+        for t, shape, dt in ((x0, (B, 13), self.tdtype), (ref, (B, 10), self.tdtype), (feet0, (B, 4, 3), self.tdtype),
+                             (footholds, (B, 2, 4, 3), self.tdtype), (gait, (B, 4), torch.int32), (feet_id, (B, 2, 4), torch.uint8),
+                             (mu, (B,), self.tdtype)):
+            if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"operand mismatch: expected {shape} {dt} contiguous on {self.device}, got "
+                                 f"{tuple(t.shape)} {t.dtype} on {t.device}")
+        out = self._outputs(B, want_X)
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self.engine.solve_batch_gait_ptr(B, x0.data_ptr(), ref.data_ptr(), feet0.data_ptr(), footholds.data_ptr(), gait.data_ptr(),
+                                         feet_id.data_ptr(), mu.data_ptr(), out["u"].data_ptr(),
+                                         out["X"].data_ptr() if want_X else None, out["status"].data_ptr(),
+                                         out["iters"].data_ptr(), out["res"].data_ptr(), st.cuda_stream)
+        return out
+
     def last_kernel_ms(self):
         return self.engine.last_kernel_ms()

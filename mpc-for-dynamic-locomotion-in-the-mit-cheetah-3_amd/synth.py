@@ -116,3 +116,58 @@ def config4(B=65536, dtype=np.float64):
 def config5(B=4096, dtype=np.float64):
     """B=4096, N=20 (seed 20250811)."""
     return make_batch(B, 20, 0.03, 20250811, ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0), dtype)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Compact gait descriptors (include/mpcqp.h, mpcqp_solve_batch_gait) and their host expansion
+# ----------------------------------------------------------------------------------------------------------------------
+def make_gait_batch(B, N=10, delta=0.03, seed=20250812, gait_names=("trot", "pronk", "amble", "gallop"), mus=(0.3, 0.5, 0.7, 1.0),
+                    stride=0.06):
+    """Same state distribution as `make_batch`, but described the way the controller knows it: measured feet, the
+    planned footholds of the current and next step (swing feet land `stride` ahead along the heading), the gait clock."""
+    rng = np.random.default_rng(seed)
+    base = make_batch(B, N, delta, seed, gait_names, mus)
+    x0 = base["x0"]
+    yaw = x0[:, 2]
+    c, s = np.cos(yaw), np.sin(yaw)
+    v_ref = np.stack([c * V_REF_BODY[0] - s * V_REF_BODY[1], s * V_REF_BODY[0] + c * V_REF_BODY[1], np.zeros(B)], axis=1)
+    com_start = np.concatenate([x0[:, 3:5], np.full((B, 1), H_COM)], axis=1)
+    ref = np.concatenate([np.zeros((B, 2)), yaw[:, None], com_start, v_ref, np.zeros((B, 1))], axis=1)
+    feet0 = base["r"][:, 0] + x0[:, None, 3:6]                       # measured feet (stage-0 lever arm + com)
+    gaits = np.asarray([GAITS[g] for g in gait_names], dtype=np.uint8)
+    fid0 = gaits[base["gait_ids"]]
+    t0 = base["t0"]
+    step_par = (t0 // (SS_TICKS + DS_TICKS)) % 2
+    fid_cur = np.where(step_par[:, None] == 0, fid0, 1 - fid0).astype(np.uint8)
+    feet_id = np.stack([fid_cur, 1 - fid_cur], axis=1).astype(np.uint8)
+    heading = np.stack([c, s, np.zeros(B)], axis=1)
+    fh0 = feet0 + rng.normal(0.0, 0.003, (B, 4, 3)) * np.array([1.0, 1.0, 0.0])
+    fh1 = np.where(fid_cur[:, :, None] == 0, fh0 + stride * heading[:, None, :], fh0)   # feet swinging now land ahead
+    gait = np.stack([t0 % (SS_TICKS + DS_TICKS), np.full(B, SS_TICKS), np.full(B, DS_TICKS), np.zeros(B, int)], axis=1).astype(np.int32)
+    return {"x0": x0, "ref": ref, "feet0": feet0, "footholds": np.stack([fh0, fh1], axis=1), "gait": gait, "feet_id": feet_id,
+            "mu": base["mu"]}
+
+
+def expand_gait_batch(g, N=10, delta=0.03):
+    """numpy expansion of the descriptors into the operator tuple (the host loop of src/mpc.py:178-254, vectorised)."""
+    x0, ref = np.asarray(g["x0"], float), np.asarray(g["ref"], float)
+    B = len(x0)
+    k = np.arange(N + 1)[None, :, None]
+    xdes = np.zeros((B, N + 1, 13))
+    xdes[:, :, 0], xdes[:, :, 1] = ref[:, None, 0], ref[:, None, 1]
+    xdes[:, :, 2] = ref[:, None, 2] + k[:, :, 0] * delta * ref[:, None, 9]
+    xdes[:, :, 3:6] = ref[:, None, 3:6] + k * delta * ref[:, None, 6:9]
+    xdes[:, :, 8] = ref[:, None, 9]
+    xdes[:, :, 9:12] = ref[:, None, 6:9]
+    xdes[:, :, 12] = x0[:, None, 12]
+    tis, ss, ds = (np.asarray(g["gait"])[:, i][:, None] for i in range(3))
+    tau = tis + np.arange(N)[None, :]
+    st = (tau >= ss + ds).astype(int)
+    tau = tau - st * (ss + ds)
+    fid = np.asarray(g["feet_id"])[np.arange(B)[:, None], st]                     # [B,N,4]
+    contact = np.where((tau < ss)[:, :, None], fid, 1).astype(np.uint8)
+    fh = np.asarray(g["footholds"], float)[np.arange(B)[:, None], st]             # [B,N,4,3]
+    r = fh - xdes[:, :N, None, 3:6]
+    r[:, 0] = np.asarray(g["feet0"], float) - x0[:, None, 3:6]
+    return {"x0": x0, "r": r, "contact": contact, "xdes": xdes, "mu": np.asarray(g["mu"], float)}
+

@@ -630,3 +630,50 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0v, const void* rv
   h->last_ms = (float)((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
   return MPCQP_OK;
 }
+
+/* Gait entry: expand the compact descriptors on the host exactly as MPC.solve does (src/mpc.py:178-254, planner queries
+ * src/footstep_planner.py:226-246), then solve as above.  Literal loops; shares nothing with the device expansion. */
+int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0v, const void* refv, const void* feet0v,
+                           const void* footholdsv, const int32_t* gait, const uint8_t* feet_id, const void* muv, void* uv,
+                           void* Xv, int32_t* status, int32_t* iters, float* res, void* stream) {
+  if (!h) return MPCQP_EINVAL;
+  if (B < 0 || (B > 0 && (!x0v || !refv || !feet0v || !footholdsv || !gait || !feet_id || !muv || !uv || !status || !iters))) {
+    snprintf(h->err, sizeof(h->err), "mpcqp_solve_batch_gait: null buffer or negative batch");
+    return MPCQP_EINVAL;
+  }
+  const int N = h->cfg.N;
+  const double d = h->cfg.delta;
+  const double *x0 = (const double*)x0v, *ref = (const double*)refv, *feet0 = (const double*)feet0v, *fh = (const double*)footholdsv;
+  double* r = (double*)malloc(sizeof(double) * (size_t)(B ? B : 1) * N * 12);
+  double* xd = (double*)malloc(sizeof(double) * (size_t)(B ? B : 1) * (N + 1) * NX);
+  uint8_t* ct = (uint8_t*)malloc((size_t)(B ? B : 1) * N * 4);
+  if (!r || !xd || !ct) { free(r); free(xd); free(ct); return MPCQP_ENOMEM; }
+  for (int64_t b = 0; b < B; b++) {
+    const double* rf = ref + b * 10;
+    const int tis = gait[b * 4 + 0], ss = gait[b * 4 + 1], ds = gait[b * 4 + 2];
+    if (N > ss + ds) { free(r); free(xd); free(ct); snprintf(h->err, sizeof(h->err), "gait: N must not exceed ss + ds"); return MPCQP_EINVAL; }
+    for (int k = 0; k <= N; k++) { /* src/mpc.py:202-214 */
+      double* xk = xd + (b * (N + 1) + k) * NX;
+      memset(xk, 0, sizeof(double) * NX);
+      xk[0] = rf[0]; xk[1] = rf[1];
+      xk[2] = rf[2] + k * d * rf[9];
+      for (int a = 0; a < 3; a++) { xk[3 + a] = rf[3 + a] + k * d * rf[6 + a]; xk[9 + a] = rf[6 + a]; }
+      xk[8] = rf[9];
+      xk[12] = x0[b * NX + 12];
+    }
+    for (int k = 0; k < N; k++) {
+      int tau = tis + k, st = 0;
+      if (tau >= ss + ds) { tau -= ss + ds; st = 1; }
+      for (int l = 0; l < 4; l++) {
+        ct[(b * N + k) * 4 + l] = (tau < ss) ? (feet_id[b * 8 + st * 4 + l] ? 1 : 0) : 1;       /* footstep_planner.py:239-246 */
+        for (int a = 0; a < 3; a++)                                                           /* src/mpc.py:218-239 */
+          r[((b * N + k) * 4 + l) * 3 + a] = k == 0 ? feet0[b * 12 + l * 3 + a] - x0[b * NX + 3 + a]
+                                                    : fh[b * 24 + st * 12 + l * 3 + a] - xd[(b * (N + 1) + k) * NX + 3 + a];
+      }
+    }
+  }
+  const int rc = mpcqp_solve_batch(h, B, x0v, r, ct, xd, muv, uv, Xv, status, iters, res, stream);
+  free(r); free(xd); free(ct);
+  return rc;
+}
+

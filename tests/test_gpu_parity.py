@@ -179,3 +179,38 @@ def test_operand_validation():
         sol.solve_batch(b["x0"].double(), b["r"], b["contact"], b["xdes"], b["mu"])
     with pytest.raises(ValueError):
         sol.solve_batch(b["x0"].cpu(), b["r"], b["contact"], b["xdes"], b["mu"])
+
+
+def test_gait_entry_point_device_side_generation(oracle_solve):
+    """mpcqp_solve_batch_gait: contact masks / lever arms / x_des generated on the device from compact descriptors
+     -- same answers as the expanded tuple through the normal entry point and as the oracle."""
+    g = mpcqp.synth.make_gait_batch(512)
+    t = mpcqp.synth.expand_gait_batch(g)
+    ref = oracle_solve(t)
+    sol = mpcqp.MPCBatch(io_dtype="f64", precision="mixed")
+    dg = sol.upload_gait(g)
+    o = sol.solve_batch_gait(dg["x0"], dg["ref"], dg["feet0"], dg["footholds"], dg["gait"], dg["feet_id"], dg["mu"], want_X=True)
+    torch.cuda.synchronize()
+    ug, Xg, stg = o["u"].cpu().numpy().copy(), o["X"].cpu().numpy().copy(), o["status"].cpu().numpy().copy()
+    dt = sol.upload(t)
+    o2 = sol.solve_batch(dt["x0"], dt["r"], dt["contact"], dt["xdes"], dt["mu"], want_X=True)
+    torch.cuda.synchronize()
+    ut, stt = o2["u"].cpu().numpy(), o2["status"].cpu().numpy()
+    ok = solved(stg)
+    assert ok.mean() >= 0.97 and np.array_equal(stg, stt)
+    assert rel_err(ug, ref["u"])[ok].max() <= 1e-4 and np.abs(Xg[ok] - ref["X"][ok]).max() <= 1e-4
+    assert rel_err(ug, ut)[ok].max() <= 5e-5          # same problem through both entry points (each is ~1e-5 from the optimum)
+    # f32 buffers through the gait entry
+    sol32 = mpcqp.MPCBatch(io_dtype="f32", precision="mixed")
+    d32 = sol32.upload_gait(g)
+    o3 = sol32.solve_batch_gait(d32["x0"], d32["ref"], d32["feet0"], d32["footholds"], d32["gait"], d32["feet_id"], d32["mu"])
+    torch.cuda.synchronize()
+    ok3 = solved(o3["status"].cpu().numpy())
+    assert ok3.mean() >= 0.97 and rel_err(o3["u"].cpu().numpy(), ref["u"])[ok3].max() <= 1e-4
+    # the entry point refuses configurations the fast path does not cover
+    s20 = mpcqp.MPCBatch(N=20)
+    e = sol32.upload_gait(mpcqp.synth.make_gait_batch(2))
+    with pytest.raises(mpcqp.MpcQpError):
+        s20.engine.solve_batch_gait_ptr(2, e["x0"].data_ptr(), e["ref"].data_ptr(), e["feet0"].data_ptr(), e["footholds"].data_ptr(),
+                                        e["gait"].data_ptr(), e["feet_id"].data_ptr(), e["mu"].data_ptr(), e["x0"].data_ptr(),
+                                        None, e["gait"].data_ptr(), e["gait"].data_ptr(), None)

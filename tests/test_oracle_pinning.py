@@ -156,3 +156,21 @@ def test_nonfinite_input_flagged(oracle_solve):
     sol = oracle_solve(b)
     assert sol["status"][2] == -1 and np.all(sol["u"][2] == 0)
     assert np.all(sol["status"][[0, 1, 3]] == 1)
+
+
+def test_gait_descriptor_expansion_host_vs_oracle(oracle_lib):
+    """The gait entry point of the checker (literal C loops) and the vectorised numpy expansion agree exactly, and the
+    expansion reproduces the planner semantics (phase = feet_id during the first ss ticks of a step, else all stance)."""
+    g = mpcqp.synth.make_gait_batch(32)
+    t = mpcqp.synth.expand_gait_batch(g)
+    eng = mpcqp.Engine(oracle_lib, oracle_lib.default_config(max_iter=4000))
+    a = eng.solve_batch_gait_host(g)
+    b = eng.solve_batch_host(t["x0"], t["r"], t["contact"], t["xdes"], t["mu"])
+    assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["X"], b["X"]) and np.array_equal(a["status"], b["status"])
+    for i in range(32):
+        tis, ss, ds = g["gait"][i][:3]
+        for k in range(10):
+            tau = tis + k
+            st = int(tau >= ss + ds); tau -= st * (ss + ds)
+            want = g["feet_id"][i, st] if tau < ss else np.ones(4, np.uint8)
+            assert np.array_equal(t["contact"][i, k], want)
