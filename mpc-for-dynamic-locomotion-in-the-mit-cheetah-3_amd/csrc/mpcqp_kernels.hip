@@ -3,23 +3,17 @@
 // Replaces, for a batch of B independent robots, the solve the reference performs once per control tick:
 // CasADi Opti('conic') -> OSQP on the QP of src/mpc.py:58-173, filled at src/mpc.py:242-255, solved at :258.
 //
-// Mapping (DESIGN.md has the derivations):
-//   * one QP per workgroup; the n x n system matrix (n = 12 N force variables) never touches LDS or HBM: it
-//     lives in registers as 3 x CW tiles, thread (leg-stage l, column chunk c) owning rows 3l..3l+2 and
-//     columns c*CW..c*CW+CW-1 (CT = 8 lanes per leg-stage, so one wave = 8 leg-stages = 2 horizon stages);
-//   * the matrix is built from closed forms: because the single-rigid-body A is nilpotent (A^3 = 0, A^2 B = 0)
-//     the condensed Hessian is H = 2 alpha I + 2 sum over stage pairs of c1[j][j'] P_i.P_i' + c0[j][j'] Q_i.Q_i'
-//     with 6-vectors P_i, Q_i per force variable (weighted angular/linear response at position and velocity
-//     level) and two N x N coefficient tables that depend only on (N, delta, discretisation);
-//   * M = H + diag is inverted in place, in registers, by the symmetric sweep operator (Gauss-Jordan without
-//     pivoting, valid for SPD): per pivot one LDS broadcast of the pivot row + one workgroup barrier;
-//   * an ADMM iteration is a register-tile x LDS-vector product, an 8-lane butterfly sum, the per-leg
-//     projection onto the friction-pyramid rows in registers, and one barrier;
-//   * gradients / residuals / predicted states come from an O(N) rollout + adjoint in the vector precision
-//     (f64 in MIXED and F64 modes) -- the dense Hessian is never needed in high precision;
-//   * optional active-set polish (OSQP's "polish" idea): the equality-constrained QP on the active rows is
-//     solved with the same build+sweep code on transformed per-variable vectors, refined against the f64
-//     structured gradient, and accepted only if it passes a KKT check.
+// This translation unit is the C-ABI of include/mpcqp.h and the dispatch between two device implementations:
+//   mpcqp_fast.h     horizon 10, ADMM + polish, fp32 matrix tiles with fp64 / fp32 structured residuals: one kernel whose
+//                    phases are separately register-allocated noinline device functions on a file-scope LDS block
+//   mpcqp_general.h  every other configuration (F64, ADMM-only, alpha = 0, horizon 20): one inlined state-machine kernel
+//   mpcqp_device.h   what they share: closed-form model pieces, the O(N) rollout + adjoint gradient, DPP reductions
+// Common design (DESIGN.md has the derivations): one QP per workgroup; the n x n system matrix (n = 12 N force variables)
+// never touches LDS or HBM -- it is built from closed forms straight into register tiles (the single-rigid-body A is
+// nilpotent, so H = 2 alpha I + 2 sum_{stage pairs} c1 P_i.P_i' + c0 Q_i.Q_i' with 6-vectors per force variable), inverted
+// in place by a symmetric sweep (one LDS broadcast + one barrier per pivot), and applied as register-tile x LDS-vector
+// products with DPP butterfly sums; gradients / residuals / predicted states come from an O(N) rollout + adjoint in
+// the vector precision; an OSQP-style active-set polish with a KKT check delivers the digits.
 
 #include "mpcqp_general.h"
 #include "mpcqp_fast.h"

@@ -214,3 +214,20 @@ def test_gait_entry_point_device_side_generation(oracle_solve):
         s20.engine.solve_batch_gait_ptr(2, e["x0"].data_ptr(), e["ref"].data_ptr(), e["feet0"].data_ptr(), e["footholds"].data_ptr(),
                                         e["gait"].data_ptr(), e["feet_id"].data_ptr(), e["mu"].data_ptr(), e["x0"].data_ptr(),
                                         None, e["gait"].data_ptr(), e["gait"].data_ptr(), None)
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_non_default_model_constants(oracle_solve, general):
+    """Nothing is tied to the Lite3 defaults: other mass / inertia / weights / force bounds / delta / alpha, both kernels."""
+    b = mpcqp.synth.make_batch(192, N=10, delta=0.02, seed=77, gait_names=("trot", "gallop"), mus=(0.4, 0.8))
+    kw = dict(m=12.5, Ibody_inv=[1 / 0.4, 1 / 0.9, 1 / 1.3], w=[2e4, 1e4, 3e4, 1e5, 2e5, 3e5, 5e3, 2e4, 1e4, 1e4, 2e4, 3e4, 0.0],
+              alpha=3e-2, f_min=5.0, f_max=150.0)
+    ref = oracle_solve(b, delta=0.02, **kw)
+    out = gpu_solve(b, delta=0.02, io="f64", precision="mixed", flags=(1 | 4) if general else 1, **kw)
+    ok = solved(out["status"])
+    assert ok.mean() >= 0.95
+    assert rel_err(out["u"], ref["u"])[ok].max() <= 1e-4
+    assert np.abs(out["X"][ok] - ref["X"][ok]).max() <= 1e-4
+    # and the changed constants do change the answer (the check above is not vacuous)
+    ref0 = oracle_solve(b, delta=0.02)
+    assert rel_err(ref["u"], ref0["u"]).max() > 1e-2
