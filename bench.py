@@ -157,6 +157,13 @@ def main():
         flops = algorithmic_flops(N, k_mean)
         achieved = flops * B / (kernel_ms * 1e-3) / 1e12
         hbm = algorithmic_bytes(N) * B / (kernel_ms * 1e-3) / 1e9
+        traffic = None     # HBM bytes per launch from the committed PMC passes (tools/pmc_hbm.sh), same workload only
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "r01_d_hbm_traffic.json")))
+            if B == 4096 and args.precision == "mixed":
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "QP solves/sec (horizon=10, 4-contact Lite3) at batch=4096", "value": value, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -169,7 +176,7 @@ def main():
                        "polish": bool(solver.cfg.flags & 1), "allgather": bool(gathered is not None),
                        "solved_fraction": solved, "admm_iters_mean": k_mean, "polish_steps_mean": float((iters // 1000).mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                          "kernel": "mpcqp_fast_solve<double,float> (one launch per solve_batch)" if args.precision == "mixed"
                          else "mpcqp_fast_solve<float,float>" if args.precision == "f32" else "mpcqp_solve_kernel<double,double,float,10>",
                          "kernel_ms": kernel_ms, "kernel_ms_last_launch": last_ms,

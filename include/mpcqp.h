@@ -58,7 +58,8 @@ extern "C" {
 
 /* flags */
 #define MPCQP_FLAG_POLISH 1u     /* active-set polish after ADMM (OSQP's `polish`; the reference leaves it off) */
-#define MPCQP_FLAG_WARM_START 2u /* keep (u, z, y) per batch slot between calls (src/mpc.py:270-271 is primal-only) */
+#define MPCQP_FLAG_WARM_START 2u /* RESERVED: per-slot (u, z, y) warm start between calls (the reference's is primal-only,
+                                    src/mpc.py:270-271); accepted and ignored by this version -- every call starts cold */
 #define MPCQP_FLAG_GENERAL_KERNEL 4u /* product library: use the single-launch general kernel even where the fast path applies */
 
 /*

@@ -6,7 +6,8 @@
 // addressing):
 //   ph_setup        operator tuple -> per-variable response vectors, linear term g
 //   ph_admm         M = H + sigma I + rho G'G -> register tiles -> in-register sweep -> K ADMM iterations (fp32),
-//                   with one early OSQP rho check (ph_ratio) that rebuilds the matrix for slowly converging QPs
+//                   with one early OSQP rho check (residuals tracked locally by the iteration) that rebuilds the matrix
+//                   for slowly converging QPs
 //   ph_polish_step  active set -> reduced matrix tiles -> sweep -> solve refined against the TV gradient -> KKT
 //   ph_output       forces / predicted states / status
 // Every phase that needs the matrix rebuilds it, so the 6 x 16 register tile is local to a phase and each phase gets
@@ -52,7 +53,8 @@ struct SmemF {
   TV wr[90], Xs[132], es[132], adj[90];
   TV uv[120], gv[120], gl[120];
   TV pu[120], py[200];
-  float ua[120], za[200], ya[200];          // last ADMM iterate (polish kernel: fallback answer + rho adaptation)
+  float ua[120], za[200], ya[200];          // last ADMM iterate (fallback answer, start of the next block)
+  float hva[120];                           // H u + g at that iterate, tracked by the iteration
   float c0[100], c1[100];
   alignas(16) float pq[120 * 12];
   float dg[120];
@@ -62,6 +64,7 @@ struct SmemF {
   float kkt[4];                             // stat, primal violation, dual violation of the last polish step
   float gmax;                               // |g|_inf
   float rho;                                // current ADMM penalty
+  float ratio;                              // OSQP residual ratio at the end of the last ADMM block
   int iters, psteps, hard;                  // bookkeeping shared by the phases
   uint8_t ct[40];
   uint8_t em[40];
@@ -368,21 +371,26 @@ template <typename TV>
 __device__ __forceinline__ void fast_admm_iters(const Tile& tile, SmemF<TV>& s, const int iters, const float rho,
                                                 const float sigma, const float relax, const float mu, const bool stance,
                                                 const float fmin, const float fmax, const float (&g3)[3], float (&u3)[3],
-                                                float (&z5)[5], float (&y5)[5], const int cc, const bool second, const int rbM) {
+                                                float (&z5)[5], float (&y5)[5], float (&hv)[3], const int cc, const bool second,
+                                                const int rbM) {
   constexpr int VP = FG::VP;
   const float BIG = 1e30f;
   const float lo0 = stance ? fmin : 0.f, hi0 = stance ? fmax : 0.f;   // src/mpc.py:151-157
   const float hiP = stance ? BIG : 0.f, loM = stance ? -BIG : 0.f;   // src/mpc.py:159-173
   const float inv_rho = 1.f / rho;
+  const float dd[3] = {sigma + 2.f * rho, sigma + 2.f * rho, sigma + rho * (1.f + 4.f * mu * mu)};   // diag(sigma I + rho G'G) of my leg
+  float w3[3];   // G'(rho z - y) of my leg: the constraint part of the right-hand side
   auto write_rhs = [&](int bsel) {
     float v[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) v[i] = rho * z5[i] - y5[i];
+    w3[0] = v[1] + v[2];
+    w3[1] = v[3] + v[4];
+    w3[2] = v[0] + mu * (-v[1] + v[2] - v[3] + v[4]);
     if ((cc & 3) == 0) {
       float* rb = s.rhs + bsel * VP;
-      rb[rbM + 0] = sigma * u3[0] - g3[0] + v[1] + v[2];
-      rb[rbM + 1] = sigma * u3[1] - g3[1] + v[3] + v[4];
-      rb[rbM + 2] = sigma * u3[2] - g3[2] + v[0] + mu * (-v[1] + v[2] - v[3] + v[4]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rb[rbM + c] = sigma * u3[c] - g3[c] + w3[c];
     }
   };
   write_rhs(0);
@@ -395,7 +403,13 @@ __device__ __forceinline__ void fast_admm_iters(const Tile& tile, SmemF<TV>& s, 
     const float zt[5] = {ut[2], ut[0] - mu * ut[2], ut[0] + mu * ut[2], ut[1] - mu * ut[2], ut[1] + mu * ut[2]};
     const float lo[5] = {lo0, loM, 0.f, loM, 0.f}, hi[5] = {hi0, 0.f, hiP, 0.f, hiP};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) u3[c] = relax * ut[c] + (1.f - relax) * u3[c];
+    for (int c = 0; c < 3; ++c) {
+      // M ut = sigma u - g + w  =>  H ut + g = sigma (u - ut) + w - rho G'G ut : the gradient of the cost follows the
+      // relaxed iterate without ever applying H (stance legs; swing legs stay at zero)
+      const float hq = stance ? sigma * u3[c] + w3[c] - dd[c] * ut[c] : 0.f;
+      hv[c] = relax * hq + (1.f - relax) * hv[c];
+      u3[c] = relax * ut[c] + (1.f - relax) * u3[c];
+    }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const float zr = relax * zt[i] + (1.f - relax) * z5[i];
@@ -410,9 +424,41 @@ __device__ __forceinline__ void fast_admm_iters(const Tile& tile, SmemF<TV>& s, 
   }
 }
 
-constexpr int ADAPT_AT = 25;             // iteration of the single early rho check
-constexpr float ADAPT_THR = 10.f, ADAPT_RHO_MAX = 30.f;
-constexpr int HARD_ITER_FACTOR = 3;      // ADMM block length of the QPs that trigger it (x check_every)
+// OSQP's rho-adaptation ratio sqrt((|r_prim| / norm_prim) / (|r_dual| / norm_dual)) from per-leg quantities held in
+// registers: hv = H u + g is tracked by the iteration itself, so no gradient evaluation is needed.  Uniform result.
+template <typename TV>
+__device__ __forceinline__ float fast_local_ratio(SmemF<TV>& s, const float mu, const float (&g3)[3], const float (&u3)[3],
+                                                  const float (&z5)[5], const float (&y5)[5], const float (&hv)[3], const int tid) {
+  const float gu[5] = {u3[2], u3[0] - mu * u3[2], u3[0] + mu * u3[2], u3[1] - mu * u3[2], u3[1] + mu * u3[2]};
+  const float Gy[3] = {y5[1] + y5[2], y5[3] + y5[4], y5[0] + mu * (-y5[1] + y5[2] - y5[3] + y5[4])};
+  float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    q[0] = fmaxf(q[0], fabsf(gu[i] - z5[i]));
+    q[2] = fmaxf(q[2], fmaxf(fabsf(gu[i]), fabsf(z5[i])));
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    q[1] = fmaxf(q[1], fabsf(hv[c] + Gy[c]));
+    q[3] = fmaxf(q[3], fmaxf(fabsf(hv[c] - g3[c]), fabsf(Gy[c])));
+  }
+  block_max<4, FG::NW>(q, s.red, tid);
+  const float sp = q[2], sd = fmaxf(q[3], s.gmax);
+  return sqrtf((q[0] / fmaxf(sp, 1e-12f)) / fmaxf(q[1] / fmaxf(sd, 1e-12f), 1e-30f));
+}
+
+#ifndef MPCQP_ADAPT_AT
+#define MPCQP_ADAPT_AT 25
+#endif
+#ifndef MPCQP_ADAPT_THR
+#define MPCQP_ADAPT_THR 10.f
+#endif
+#ifndef MPCQP_HARD_ITER_FACTOR
+#define MPCQP_HARD_ITER_FACTOR 2
+#endif
+constexpr int ADAPT_AT = MPCQP_ADAPT_AT;             // iteration of the single early rho check
+constexpr float ADAPT_THR = MPCQP_ADAPT_THR, ADAPT_RHO_MAX = 30.f;
+constexpr int HARD_ITER_FACTOR = MPCQP_HARD_ITER_FACTOR;      // ADMM block length of the QPs that trigger it (x check_every)
 constexpr int HARD_POLISH_FACTOR = 2;    // ... and their polish-step budget (x polish_max)
 
 // ------------------------------------------------------------------------------------------------------ phases
@@ -422,51 +468,13 @@ MPCQP_PHASE int ph_setup(const DevCfg* __restrict__ cfgp, const double* __restri
   const int tid = threadIdx.x;
   const int bad = GAIT ? fast_load_gait<TV, TIO>(s, in, *cfgp, b, tid) : fast_load_tuple<TV, TIO>(s, in, b, tid);
   if (fast_setup<TV>(s, *cfgp, ctab, bad, tid)) return 1;
-  for (int i = tid; i < FG::n; i += FG::NT) { s.ua[i] = 0.f; s.pu[i] = (TV)0; }
+  for (int i = tid; i < FG::n; i += FG::NT) { s.ua[i] = 0.f; s.pu[i] = (TV)0; s.hva[i] = (float)s.gl[i]; }   // H 0 + g = g
   for (int i = tid; i < FG::NL * 5; i += FG::NT) { s.za[i] = 0.f; s.ya[i] = 0.f; s.py[i] = (TV)0; }
   float q[1] = {tid < FG::n ? fabsf((float)s.gl[tid]) : 0.f};
   block_max<1, FG::NW>(q, s.red, tid);
   if (tid == 0) { s.gmax = q[0]; s.rho = (float)cfgp->rho; s.iters = 0; s.psteps = 0; s.hard = 0; }
   __syncthreads();
   return 0;
-}
-
-// OSQP's rho-adaptation ratio sqrt((|r_prim| / norm_prim) / (|r_dual| / norm_dual)) of the ADMM iterate in
-// s.ua / s.za / s.ya.  Uniform result.
-template <typename TV>
-MPCQP_PHASE float ph_ratio() {
-  constexpr int N = FG::N, NW = FG::NW;
-  SmemF<TV>& s = lds<TV>();
-  const Lane L;
-  const int tid = L.tid, myleg = L.myleg, row0 = L.row0;
-  const TV muv = s.mu;
-  if ((L.cc & 3) == 0) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) s.uv[row0 + c] = (TV)s.ua[row0 + c];
-  }
-  __syncthreads();
-  struct_grad<SmemF<TV>, TV, N>(s, tid);
-  float q[4] = {0.f, 0.f, 0.f, 0.f};
-  {
-    const TV U0 = (TV)s.ua[row0], U1 = (TV)s.ua[row0 + 1], U2 = (TV)s.ua[row0 + 2];
-    const TV gu[5] = {U2, U0 - muv * U2, U0 + muv * U2, U1 - muv * U2, U1 + muv * U2};
-    const float* ya = s.ya + myleg * 5;
-    const TV Gy[3] = {(TV)ya[1] + (TV)ya[2], (TV)ya[3] + (TV)ya[4], (TV)ya[0] + muv * (-(TV)ya[1] + (TV)ya[2] - (TV)ya[3] + (TV)ya[4])};
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      q[0] = fmaxf(q[0], fabsf((float)(gu[i] - (TV)s.za[myleg * 5 + i])));
-      q[2] = fmaxf(q[2], fmaxf(fabsf((float)gu[i]), fabsf(s.za[myleg * 5 + i])));
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const TV gr = s.gv[row0 + c];
-      q[1] = fmaxf(q[1], fabsf((float)(gr + Gy[c])));
-      q[3] = fmaxf(q[3], fmaxf(fabsf((float)(gr - s.gl[row0 + c])), fabsf((float)Gy[c])));
-    }
-  }
-  block_max<4, NW>(q, s.red, tid);
-  const float sp = q[2], sd = fmaxf(q[3], s.gmax);
-  return sqrtf((q[0] / fmaxf(sp, 1e-12f)) / fmaxf(q[1] / fmaxf(sd, 1e-12f), 1e-30f));
 }
 
 // One ADMM block from the state in s.ua / s.za / s.ya with penalty s.rho: matrix tiles -> sweep -> iterations.
@@ -481,9 +489,9 @@ MPCQP_PHASE void ph_admm(const DevCfg* __restrict__ cfgp, const int adapt) {
   const float mu = (float)s.mu, sigma = (float)cfg.sigma, relax = (float)cfg.relax;
   const float fmin = (float)s.cf.fmin, fmax = (float)s.cf.fmax;
   float rho = s.rho;
-  float g3[3], u3[3], z5[5], y5[5];
+  float g3[3], u3[3], z5[5], y5[5], hv[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { g3[c] = (float)s.gl[L.row0 + c]; u3[c] = s.ua[L.row0 + c]; }
+  for (int c = 0; c < 3; ++c) { g3[c] = (float)s.gl[L.row0 + c]; u3[c] = s.ua[L.row0 + c]; hv[c] = s.hva[L.row0 + c]; }
 #pragma unroll
   for (int i = 0; i < 5; ++i) { z5[i] = s.za[5 * L.myleg + i]; y5[i] = s.ya[5 * L.myleg + i]; }
   int K = cfg.check_every;
@@ -504,18 +512,11 @@ MPCQP_PHASE void ph_admm(const DevCfg* __restrict__ cfgp, const int adapt) {
       STAMP(3);
       need_build = false;
     }
-    fast_admm_iters<TV>(tile, s, seg_end - it, rho, sigma, relax, mu, stance, fmin, fmax, g3, u3, z5, y5, L.cc, L.second, L.rbM);
+    fast_admm_iters<TV>(tile, s, seg_end - it, rho, sigma, relax, mu, stance, fmin, fmax, g3, u3, z5, y5, hv, L.cc, L.second, L.rbM);
     it = seg_end;
     STAMP(4);
-    if ((L.cc & 3) == 0) {   // publish the iterate
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { s.ua[L.row0 + c] = u3[c]; s.pu[L.row0 + c] = (TV)u3[c]; }
-#pragma unroll
-      for (int i = 0; i < 5; ++i) { s.za[5 * L.myleg + i] = z5[i]; s.ya[5 * L.myleg + i] = y5[i]; s.py[5 * L.myleg + i] = (TV)y5[i]; }
-    }
-    __syncthreads();
     if (it >= K) break;
-    const float ratio = ph_ratio<TV>();   // separate register allocation; the tile is saved around the call
+    const float ratio = fast_local_ratio<TV>(s, mu, g3, u3, z5, y5, hv, L.tid);   // early rho check, no gradient call
     if (ratio > ADAPT_THR) {              // uniform
       rho = fminf(rho * ratio, ADAPT_RHO_MAX);
       need_build = true;
@@ -525,7 +526,14 @@ MPCQP_PHASE void ph_admm(const DevCfg* __restrict__ cfgp, const int adapt) {
     seg_end = K;
     STAMP(5);
   }
-  if (L.tid == 0) { s.rho = rho; s.iters += K; s.hard |= hard; }
+  const float end_ratio = fast_local_ratio<TV>(s, mu, g3, u3, z5, y5, hv, L.tid);   // for the next block's rho, should one be needed
+  if ((L.cc & 3) == 0) {   // publish the iterate
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s.ua[L.row0 + c] = u3[c]; s.pu[L.row0 + c] = (TV)u3[c]; s.hva[L.row0 + c] = hv[c]; }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { s.za[5 * L.myleg + i] = z5[i]; s.ya[5 * L.myleg + i] = y5[i]; s.py[5 * L.myleg + i] = (TV)y5[i]; }
+  }
+  if (L.tid == 0) { s.rho = rho; s.iters += K; s.hard |= hard; s.ratio = end_ratio; }
   __syncthreads();
 }
 
@@ -743,7 +751,7 @@ mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ cta
     for (int ps = 0; ps < budget && !ok; ++ps) ok = ph_polish_step<TV>();
     if (ok || s.iters >= max_iter) break;
     // not solved: OSQP's rho adaptation from the residuals of the last ADMM iterate, then another block
-    const float ratio = ph_ratio<TV>();
+    const float ratio = s.ratio;
     if (tid == 0 && isfinite(ratio) && (ratio > 2.f || ratio < 0.5f)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
     __syncthreads();
   }
