@@ -138,6 +138,16 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
                            const void* footholds, const int32_t* gait, const uint8_t* feet_id, const void* mu,
                            void* u_out, void* X_out, int32_t* status, int32_t* iters, float* res, void* stream);
 
+/*
+ * The step right after the solve in the reference's caller (ground_controller, src/main.py:205-214): joint torques of the
+ * four legs from the stage-0 forces, tau_leg = J_leg^T (-f_leg).
+ *   u    T [B,N,12]    as written by mpcqp_solve_batch (only stage 0 is read)
+ *   jac  T [B,4,3,3]   world-frame 3x3 linear Jacobian block of each leg, row-major (the `getLinearJacobian(...)[:, 6:9]`
+ *                      etc. slices of src/main.py:205-210; this engine does not compute kinematics)
+ *   tau  T [B,4,3]     HipX, HipY, Knee torque per leg
+ */
+int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* u, const void* jac, void* tau, void* stream);
+
 /* Duration in milliseconds of the most recent solve_batch's kernel(s), measured with HIP events recorded on
  * `stream` around the launch; blocks until that work has finished.  Oracle: wall time of the call. */
 int mpcqp_last_kernel_ms(mpcqp_handle h, float* ms);

@@ -25,7 +25,7 @@ FLAG_POLISH, FLAG_WARM_START, FLAG_GENERAL_KERNEL = 1, 2, 4
 
 EXPORTED_SYMBOLS = (
     "mpcqp_version", "mpcqp_default_config", "mpcqp_create", "mpcqp_destroy", "mpcqp_solve_batch",
-    "mpcqp_solve_batch_gait", "mpcqp_last_kernel_ms", "mpcqp_last_error",
+    "mpcqp_solve_batch_gait", "mpcqp_torque_map", "mpcqp_last_kernel_ms", "mpcqp_last_error",
 )
 
 
@@ -72,6 +72,8 @@ class Library:
         L.mpcqp_solve_batch.restype = c_int32
         L.mpcqp_solve_batch_gait.argtypes = [c_void_p, c_int64] + [c_void_p] * 13
         L.mpcqp_solve_batch_gait.restype = c_int32
+        L.mpcqp_torque_map.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
+        L.mpcqp_torque_map.restype = c_int32
         L.mpcqp_last_kernel_ms.argtypes = [c_void_p, ctypes.POINTER(c_float)]
         L.mpcqp_last_kernel_ms.restype = c_int32
         L.mpcqp_last_error.argtypes = [c_void_p]
@@ -135,6 +137,11 @@ class Engine:
                                                      X_out or None, status, iters, res or None, stream or None)
         if rc != 0:
             raise MpcQpError(f"mpcqp_solve_batch_gait failed with code {rc}: {self.last_error()}")
+
+    def torque_map_ptr(self, B, u, jac, tau, stream=0):
+        rc = self.library.lib.mpcqp_torque_map(self._h, int(B), u, jac, tau, stream or None)
+        if rc != 0:
+            raise MpcQpError(f"mpcqp_torque_map failed with code {rc}: {self.last_error()}")
 
     def last_kernel_ms(self) -> float:
         ms = c_float()

@@ -22,6 +22,26 @@
 #include <cstring>
 #include <new>
 
+namespace {
+
+// tau[b][l] = J[b][l]^T (-f[b][l]) for the four legs of stage 0 (src/main.py:212-214).  Element-wise, HBM-bound:
+// one thread per (robot, leg), 9 + 3 loads and 3 stores; consecutive threads touch consecutive 48 / 12-byte records.
+template <typename TIO>
+__global__ void __launch_bounds__(256)
+mpcqp_torque_kernel(const TIO* __restrict__ u, const TIO* __restrict__ jac, TIO* __restrict__ tau, const int64_t B, const int N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // i = 4 b + leg
+  if (i >= 4 * B) return;
+  const int64_t b = i / 4;
+  const int l = (int)(i % 4);
+  const TIO* f = u + b * N * 12 + 3 * l;       // stage-0 force of this leg
+  const TIO* J = jac + i * 9;                  // 3x3, row-major, world-frame linear Jacobian block of the leg
+  const TIO fx = -f[0], fy = -f[1], fz = -f[2];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) tau[i * 3 + q] = J[0 * 3 + q] * fx + J[1 * 3 + q] * fy + J[2 * 3 + q] * fz;
+}
+
+}  // namespace
+
 // ======================================================================================================
 // C-ABI (include/mpcqp.h)
 // ======================================================================================================
@@ -263,6 +283,23 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
   he = hipEventRecord(h->ev1, st);
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
   h->timed = true;
+  return MPCQP_OK;
+}
+
+int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* u, const void* jac, void* tau, void* stream) {
+  if (!h) return MPCQP_EINVAL;
+  if (B < 0 || B > 0x1fffffff) return fail(h, MPCQP_EINVAL, "mpcqp_torque_map: batch size out of range");
+  if (B > 0 && (!u || !jac || !tau)) return fail(h, MPCQP_EINVAL, "mpcqp_torque_map: null buffer");
+  if (B == 0) return MPCQP_OK;
+  const dim3 grid((unsigned)((4 * B + 255) / 256));
+  if (h->cfg.dtype == MPCQP_DTYPE_F64)
+    hipLaunchKernelGGL((mpcqp_torque_kernel<double>), grid, dim3(256), 0, (hipStream_t)stream, (const double*)u, (const double*)jac,
+                       (double*)tau, B, h->cfg.N);
+  else
+    hipLaunchKernelGGL((mpcqp_torque_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)u, (const float*)jac,
+                       (float*)tau, B, h->cfg.N);
+  const hipError_t he = hipGetLastError();
+  if (he != hipSuccess) return fail(h, MPCQP_EHIP, "torque kernel launch", he);
   return MPCQP_OK;
 }
 

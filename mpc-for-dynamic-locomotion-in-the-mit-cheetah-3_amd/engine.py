@@ -101,5 +101,16 @@ class MPCBatch:
                                          out["iters"].data_ptr(), out["res"].data_ptr(), st.cuda_stream)
         return out
 
+    def torque_map(self, u, jac, stream=None):
+        """tau[B,4,3] = J^T (-f) of the stage-0 forces (src/main.py:212-214); jac[B,4,3,3] world-frame leg Jacobians."""
+        torch = _torch()
+        B = int(u.shape[0])
+        if tuple(jac.shape) != (B, 4, 3, 3) or jac.dtype != self.tdtype or u.dtype != self.tdtype or not jac.is_contiguous():
+            raise ValueError("jac must be a contiguous [B,4,3,3] tensor of the engine's dtype")
+        tau = torch.empty((B, 4, 3), dtype=self.tdtype, device=self.device)
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self.engine.torque_map_ptr(B, u.data_ptr(), jac.data_ptr(), tau.data_ptr(), st.cuda_stream)
+        return tau
+
     def last_kernel_ms(self):
         return self.engine.last_kernel_ms()

@@ -677,3 +677,23 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0v, const voi
   return rc;
 }
 
+/* src/main.py:212-214: tau[leg] = J[leg].T @ -forces[leg]; stage-0 forces only. */
+int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* uv, const void* jacv, void* tauv, void* stream) {
+  (void)stream;
+  if (!h || B < 0 || (B > 0 && (!uv || !jacv || !tauv))) return MPCQP_EINVAL;
+  const double *u = (const double*)uv, *jac = (const double*)jacv;
+  double* tau = (double*)tauv;
+  const int N = h->cfg.N;
+  for (int64_t b = 0; b < B; b++)
+    for (int l = 0; l < 4; l++) {
+      const double* f = u + b * N * NU + 3 * l;
+      const double* J = jac + (b * 4 + l) * 9;
+      for (int q = 0; q < 3; q++) {
+        double s = 0;
+        for (int a = 0; a < 3; a++) s += J[a * 3 + q] * -f[a];
+        tau[(b * 4 + l) * 3 + q] = s;
+      }
+    }
+  return MPCQP_OK;
+}
+

@@ -231,3 +231,17 @@ def test_non_default_model_constants(oracle_solve, general):
     # and the changed constants do change the answer (the check above is not vacuous)
     ref0 = oracle_solve(b, delta=0.02)
     assert rel_err(ref["u"], ref0["u"]).max() > 1e-2
+
+
+def test_torque_map_epilogue():
+    """tau = J^T (-f) of the stage-0 forces (src/main.py:212-214), batched on the device, against numpy."""
+    rng = np.random.default_rng(3)
+    for io, tol in (("f64", 1e-12), ("f32", 1e-4)):
+        sol = mpcqp.MPCBatch(io_dtype=io)
+        B = 1000
+        u = rng.normal(0, 30, (B, 10, 12)); J = rng.normal(0, 0.2, (B, 4, 3, 3))
+        tu = torch.as_tensor(u, dtype=sol.tdtype, device="cuda"); tj = torch.as_tensor(J, dtype=sol.tdtype, device="cuda").contiguous()
+        tau = sol.torque_map(tu, tj)
+        torch.cuda.synchronize()
+        want = np.einsum("blaq,bla->blq", J, -u[:, 0].reshape(B, 4, 3))
+        assert np.abs(tau.cpu().numpy() - want).max() <= tol * 30

@@ -174,3 +174,17 @@ def test_gait_descriptor_expansion_host_vs_oracle(oracle_lib):
             st = int(tau >= ss + ds); tau -= st * (ss + ds)
             want = g["feet_id"][i, st] if tau < ss else np.ones(4, np.uint8)
             assert np.array_equal(t["contact"][i, k], want)
+
+
+def test_torque_map_matches_reference_expression(oracle_lib):
+    """tau[leg] = J[leg].T @ -forces[leg] (src/main.py:212-214) through the checker's C-ABI entry."""
+    import ctypes
+    rng = np.random.default_rng(5)
+    B = 7
+    u = np.ascontiguousarray(rng.normal(0, 30, (B, 10, 12))); J = np.ascontiguousarray(rng.normal(0, 0.2, (B, 4, 3, 3)))
+    tau = np.zeros((B, 4, 3))
+    eng = mpcqp.Engine(oracle_lib, oracle_lib.default_config())
+    eng.torque_map_ptr(B, u.ctypes.data, J.ctypes.data, tau.ctypes.data)
+    for b in range(B):
+        for l in range(4):
+            assert np.allclose(tau[b, l], J[b, l].T @ -u[b, 0, 3 * l:3 * l + 3], atol=1e-13)
