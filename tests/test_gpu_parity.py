@@ -245,3 +245,15 @@ def test_torque_map_epilogue():
         torch.cuda.synchronize()
         want = np.einsum("blaq,bla->blq", J, -u[:, 0].reshape(B, 4, 3))
         assert np.abs(tau.cpu().numpy() - want).max() <= tol * 30
+
+
+@pytest.mark.parametrize("alpha,precision,min_solved", [(1.0, "mixed", 0.99), (1e-3, "mixed", 0.93), (1e-4, "f64", 0.9)])
+def test_regulariser_sweep(oracle_solve, alpha, precision, min_solved):
+    """`solved` must imply the 1e-4 band for any force regulariser alpha (conditioning ~ 1 / alpha): the polish acceptance
+    scales with the curvature 2 alpha.  Small alpha needs the all-fp64 mode (fp32 tiles stop being a contraction)."""
+    b = mpcqp.synth.config3(256)
+    ref = oracle_solve(b, alpha=alpha, max_iter=200000)
+    out = gpu_solve(b, io="f64", precision=precision, alpha=alpha, max_iter=1000 if precision == "f64" else 400)
+    ok = solved(out["status"])
+    assert ok.mean() >= min_solved, ok.mean()
+    assert rel_err(out["u"], ref["u"])[ok].max() <= 1e-4
