@@ -70,12 +70,14 @@ struct SmemF {
   uint8_t em[40];
 };
 
-// The workgroup's LDS block.  File scope so that the noinline phase functions address it directly (ds_*).
-__shared__ SmemF<float> g_lds_f;
-__shared__ SmemF<double> g_lds_d;
-template <typename TV> __device__ __forceinline__ SmemF<TV>& lds();
-template <> __device__ __forceinline__ SmemF<float>& lds<float>() { return g_lds_f; }
-template <> __device__ __forceinline__ SmemF<double>& lds<double>() { return g_lds_d; }
+// The workgroup's LDS block.  File scope so that the noinline phase functions address it directly (ds_*); one raw
+// buffer shared by both instantiations.  The library is built with -amdgpu-lower-module-lds-strategy=module, which
+// gives the block the same fixed address in every kernel: with the default (a per-kernel offset table, because the
+// phase functions are reachable from several kernels) the callees re-loaded the block's base from memory inside the
+// sweep -- one scalar load + wait on the critical path of every pivot.
+__shared__ __attribute__((aligned(16))) unsigned char g_lds_raw[sizeof(SmemF<double>)];
+static_assert(sizeof(SmemF<double>) >= sizeof(SmemF<float>), "raw LDS block must hold either instantiation");
+template <typename TV> __device__ __forceinline__ SmemF<TV>& lds() { return *reinterpret_cast<SmemF<TV>*>(g_lds_raw); }
 
 struct Lane {   // who am I inside the workgroup
   int tid, grp, cc, myleg, row0, rbA, rbB, rbM;

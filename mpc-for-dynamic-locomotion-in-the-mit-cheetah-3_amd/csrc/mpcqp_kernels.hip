@@ -75,16 +75,19 @@ hipError_t launch(const mpcqp_engine* e, int64_t B, const void* x0, const void* 
   return hipGetLastError();
 }
 
+#ifndef MPCQP_DEBUG_DYN_LDS
+#define MPCQP_DEBUG_DYN_LDS 0   // occupancy experiments only: extra dynamic LDS per workgroup
+#endif
 // Fast path (mpcqp_fast.h): one launch, one QP per workgroup, phases as separately register-allocated device functions.
 template <typename TIO, bool GAIT>
 hipError_t launch_fast(const mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
                        float* res, hipStream_t s) {
   const dim3 grid((unsigned)B);
   if (e->cfg.precision == MPCQP_PREC_MIXED)
-    hipLaunchKernelGGL((mpcqp_fast_solve<double, TIO, GAIT>), grid, dim3(FG::NT), 0, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
+    hipLaunchKernelGGL((mpcqp_fast_solve<double, TIO, GAIT>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
                        st, it, res);
   else
-    hipLaunchKernelGGL((mpcqp_fast_solve<float, TIO, GAIT>), grid, dim3(FG::NT), 0, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
+    hipLaunchKernelGGL((mpcqp_fast_solve<float, TIO, GAIT>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
                        st, it, res);
   return hipGetLastError();
 }
