@@ -366,84 +366,114 @@ __device__ __forceinline__ void fast_describe(SmemF<TV>& s, int myleg, int a, bo
 }
 
 // ------------------------------------------------------------------------------------------------------ ADMM block
-// `iters` iterations of OSQP algorithm 1 on the rows  fz | fx - mu fz | fx + mu fz | fy - mu fz | fy + mu fz  of my
-// leg-stage (src/mpc.py:138-173).  State (u, z, y) in registers, right-hand sides double-buffered in LDS, one barrier
-// per iteration.  tile = -M^{-1}.
+// OSQP algorithm 1 on the rows  fz | fx - mu fz | fx + mu fz | fy - mu fz | fy + mu fz  of a leg-stage
+// (src/mpc.py:138-173).  The leg-stage's state is spread over its four lanes so that the per-iteration update is one
+// short instruction stream instead of the whole leg replicated on every lane (the update, not the mat-vec, was the
+// longer half of an iteration):
+//   lane q = 0: component fx, rows A = fx - mu fz <= 0 and B = fx + mu fz >= 0
+//   lane q = 1: component fy, rows A = fy - mu fz <= 0 and B = fy + mu fz >= 0
+//   lane q = 2: component fz, row  A = fmin <= fz <= fmax (row B is an inert dummy);  lane 3 mirrors lane 2, never writes
+// The only cross-lane traffic is the mu-coupling of the fz component (two quad broadcasts).
+struct LegLane {
+  int q, comp, rowA, rowB;              // role, own component (0..2), own rows in the 5-row layout (rowB < 0: none)
+  float u, hv, g, w;                    // own component: iterate, H u + g, linear term, G'(rho z - y)
+  float zA, yA, zB, yB;                 // own constraint rows
+  float mA, mB, aB, kz, loA, hiA, loB, hiB;
+
+  __device__ __forceinline__ LegLane(int cc, bool stance, float mu, float fmin, float fmax) {
+    const float BIG = 1e30f;
+    q = cc & 3;
+    comp = q < 2 ? q : 2;
+    rowA = q == 0 ? 1 : (q == 1 ? 3 : 0);
+    rowB = q == 0 ? 2 : (q == 1 ? 4 : -1);
+    const bool tang = q < 2;
+    mA = tang ? -mu : 0.f;  mB = tang ? mu : 0.f;  aB = tang ? 1.f : 0.f;  kz = tang ? 0.f : mu;
+    loA = !stance ? 0.f : (tang ? -BIG : fmin);   hiA = !stance ? 0.f : (tang ? 0.f : fmax);   // src/mpc.py:151-173
+    loB = 0.f;                                     hiB = (stance && tang) ? BIG : 0.f;
+  }
+  template <typename SM>
+  __device__ __forceinline__ void load(const SM& s, int myleg) {
+    const int i = 3 * myleg + comp;
+    u = s.ua[i]; hv = s.hva[i]; g = (float)s.gl[i];
+    zA = s.za[5 * myleg + rowA]; yA = s.ya[5 * myleg + rowA];
+    zB = rowB >= 0 ? s.za[5 * myleg + rowB] : 0.f; yB = rowB >= 0 ? s.ya[5 * myleg + rowB] : 0.f;
+    w = 0.f;
+  }
+  template <typename SM, typename TV>
+  __device__ __forceinline__ void publish(SM& s, int myleg) const {
+    if (q < 3) {
+      const int i = 3 * myleg + comp;
+      s.ua[i] = u; s.pu[i] = (TV)u; s.hva[i] = hv;
+      s.za[5 * myleg + rowA] = zA; s.ya[5 * myleg + rowA] = yA; s.py[5 * myleg + rowA] = (TV)yA;
+      if (rowB >= 0) { s.za[5 * myleg + rowB] = zB; s.ya[5 * myleg + rowB] = yB; s.py[5 * myleg + rowB] = (TV)yB; }
+    }
+  }
+  // G'(rho z - y) of my component from my rows (+ the mu-coupled part of the tangential lanes on the fz lanes)
+  __device__ __forceinline__ void update_w(float rho) {
+    const float vA = rho * zA - yA, vB = rho * zB - yB;
+    const float d = vB - vA;
+    const float dx = dpp_mov<0x00>(d), dy = dpp_mov<0x55>(d);   // quad broadcasts of lanes 0 and 1
+    w = fmaf(kz, dx + dy, vA + vB);
+  }
+};
+
+// `iters` iterations; state in registers, right-hand sides double-buffered in LDS, one barrier per iteration.
+// tile = -M^{-1}.  hv follows H u + g without applying H: M ut = sigma u - g + w  =>  H ut + g = sigma (u - ut) + w - rho G'G ut.
 template <typename TV>
 __device__ __forceinline__ void fast_admm_iters(const Tile& tile, SmemF<TV>& s, const int iters, const float rho,
                                                 const float sigma, const float relax, const float mu, const bool stance,
-                                                const float fmin, const float fmax, const float (&g3)[3], float (&u3)[3],
-                                                float (&z5)[5], float (&y5)[5], float (&hv)[3], const int cc, const bool second,
-                                                const int rbM) {
+                                                LegLane& L, const int cc, const bool second, const int rbM) {
   constexpr int VP = FG::VP;
-  const float BIG = 1e30f;
-  const float lo0 = stance ? fmin : 0.f, hi0 = stance ? fmax : 0.f;   // src/mpc.py:151-157
-  const float hiP = stance ? BIG : 0.f, loM = stance ? -BIG : 0.f;   // src/mpc.py:159-173
-  const float inv_rho = 1.f / rho;
-  const float dd[3] = {sigma + 2.f * rho, sigma + 2.f * rho, sigma + rho * (1.f + 4.f * mu * mu)};   // diag(sigma I + rho G'G) of my leg
-  float w3[3];   // G'(rho z - y) of my leg: the constraint part of the right-hand side
-  auto write_rhs = [&](int bsel) {
-    float v[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) v[i] = rho * z5[i] - y5[i];
-    w3[0] = v[1] + v[2];
-    w3[1] = v[3] + v[4];
-    w3[2] = v[0] + mu * (-v[1] + v[2] - v[3] + v[4]);
-    if ((cc & 3) == 0) {
-      float* rb = s.rhs + bsel * VP;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) rb[rbM + c] = sigma * u3[c] - g3[c] + w3[c];
-    }
-  };
-  write_rhs(0);
+  const float inv_rho = 1.f / rho, om = 1.f - relax;
+  const float dd = L.comp == 2 ? sigma + rho * (1.f + 4.f * mu * mu) : sigma + 2.f * rho;   // diag(sigma I + rho G'G), my component
+  const float sten = stance ? 1.f : 0.f;
+  L.update_w(rho);
+  if (L.q < 3) s.rhs[rbM + L.comp] = fmaf(sigma, L.u, L.w - L.g);
   __syncthreads();
   int buf = 0;
   for (int it = 0; it < iters; ++it) {
     float sum[6];
     fast_matvec(tile, s.rhs + buf * VP, cc, sum);
-    const float ut[3] = {second ? sum[3] : sum[0], second ? sum[4] : sum[1], second ? sum[5] : sum[2]};
-    const float zt[5] = {ut[2], ut[0] - mu * ut[2], ut[0] + mu * ut[2], ut[1] - mu * ut[2], ut[1] + mu * ut[2]};
-    const float lo[5] = {lo0, loM, 0.f, loM, 0.f}, hi[5] = {hi0, 0.f, hiP, 0.f, hiP};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      // M ut = sigma u - g + w  =>  H ut + g = sigma (u - ut) + w - rho G'G ut : the gradient of the cost follows the
-      // relaxed iterate without ever applying H (stance legs; swing legs stay at zero)
-      const float hq = stance ? sigma * u3[c] + w3[c] - dd[c] * ut[c] : 0.f;
-      hv[c] = relax * hq + (1.f - relax) * hv[c];
-      u3[c] = relax * ut[c] + (1.f - relax) * u3[c];
+    const float t0 = second ? sum[3] : sum[0], t1 = second ? sum[4] : sum[1], utz = second ? sum[5] : sum[2];
+    const float utc = L.q == 0 ? t0 : (L.q == 1 ? t1 : utz);
+    const float hq = sten * fmaf(-dd, utc, fmaf(sigma, L.u, L.w));
+    L.hv = fmaf(relax, hq, om * L.hv);
+    L.u = fmaf(relax, utc, om * L.u);
+    {
+      const float gA = fmaf(L.mA, utz, utc);
+      const float zr = fmaf(relax, gA, om * L.zA);
+      const float zn = fminf(fmaxf(fmaf(L.yA, inv_rho, zr), L.loA), L.hiA);
+      L.yA = fmaf(rho, zr - zn, L.yA);
+      L.zA = zn;
     }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const float zr = relax * zt[i] + (1.f - relax) * z5[i];
-      float zn = zr + y5[i] * inv_rho;
-      zn = zn < lo[i] ? lo[i] : (zn > hi[i] ? hi[i] : zn);
-      y5[i] += rho * (zr - zn);
-      z5[i] = zn;
+    {
+      const float gB = fmaf(L.mB, utz, L.aB * utc);
+      const float zr = fmaf(relax, gB, om * L.zB);
+      const float zn = fminf(fmaxf(fmaf(L.yB, inv_rho, zr), L.loB), L.hiB);
+      L.yB = fmaf(rho, zr - zn, L.yB);
+      L.zB = zn;
     }
+    L.update_w(rho);
     buf ^= 1;
-    write_rhs(buf);
+    if (L.q < 3) s.rhs[buf * VP + rbM + L.comp] = fmaf(sigma, L.u, L.w - L.g);
     __syncthreads();
   }
 }
 
-// OSQP's rho-adaptation ratio sqrt((|r_prim| / norm_prim) / (|r_dual| / norm_dual)) from per-leg quantities held in
-// registers: hv = H u + g is tracked by the iteration itself, so no gradient evaluation is needed.  Uniform result.
+// OSQP's rho-adaptation ratio sqrt((|r_prim| / norm_prim) / (|r_dual| / norm_dual)) from the lane-distributed state:
+// hv = H u + g is tracked by the iteration itself, so no gradient evaluation is needed.  Uniform result.
 template <typename TV>
-__device__ __forceinline__ float fast_local_ratio(SmemF<TV>& s, const float mu, const float (&g3)[3], const float (&u3)[3],
-                                                  const float (&z5)[5], const float (&y5)[5], const float (&hv)[3], const int tid) {
-  const float gu[5] = {u3[2], u3[0] - mu * u3[2], u3[0] + mu * u3[2], u3[1] - mu * u3[2], u3[1] + mu * u3[2]};
-  const float Gy[3] = {y5[1] + y5[2], y5[3] + y5[4], y5[0] + mu * (-y5[1] + y5[2] - y5[3] + y5[4])};
-  float q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    q[0] = fmaxf(q[0], fabsf(gu[i] - z5[i]));
-    q[2] = fmaxf(q[2], fmaxf(fabsf(gu[i]), fabsf(z5[i])));
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    q[1] = fmaxf(q[1], fabsf(hv[c] + Gy[c]));
-    q[3] = fmaxf(q[3], fmaxf(fabsf(hv[c] - g3[c]), fabsf(Gy[c])));
-  }
+__device__ __forceinline__ float fast_local_ratio(SmemF<TV>& s, const LegLane& L, const int tid) {
+  const float uz = dpp_mov<0xAA>(L.u);                            // quad broadcast of the fz lane
+  const float guA = fmaf(L.mA, uz, L.u), guB = fmaf(L.mB, uz, L.aB * L.u);
+  const float e = L.yB - L.yA;
+  const float ex = dpp_mov<0x00>(e), ey = dpp_mov<0x55>(e);
+  const float Gy = fmaf(L.kz, ex + ey, L.yA + L.yB);              // (G'y) of my component
+  float q[4];
+  q[0] = fmaxf(fabsf(guA - L.zA), fabsf(guB - L.zB));
+  q[2] = fmaxf(fmaxf(fabsf(guA), fabsf(L.zA)), fmaxf(fabsf(guB), fabsf(L.zB)));
+  q[1] = fabsf(L.hv + Gy);
+  q[3] = fmaxf(fabsf(L.hv - L.g), fabsf(Gy));
   block_max<4, FG::NW>(q, s.red, tid);
   const float sp = q[2], sd = fmaxf(q[3], s.gmax);
   return sqrtf((q[0] / fmaxf(sp, 1e-12f)) / fmaxf(q[1] / fmaxf(sd, 1e-12f), 1e-30f));
@@ -491,11 +521,8 @@ MPCQP_PHASE void ph_admm(const DevCfg* __restrict__ cfgp, const int adapt) {
   const float mu = (float)s.mu, sigma = (float)cfg.sigma, relax = (float)cfg.relax;
   const float fmin = (float)s.cf.fmin, fmax = (float)s.cf.fmax;
   float rho = s.rho;
-  float g3[3], u3[3], z5[5], y5[5], hv[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { g3[c] = (float)s.gl[L.row0 + c]; u3[c] = s.ua[L.row0 + c]; hv[c] = s.hva[L.row0 + c]; }
-#pragma unroll
-  for (int i = 0; i < 5; ++i) { z5[i] = s.za[5 * L.myleg + i]; y5[i] = s.ya[5 * L.myleg + i]; }
+  LegLane A(L.cc, stance, mu, fmin, fmax);
+  A.load(s, L.myleg);
   int K = cfg.check_every;
   int it = 0, seg_end = (adapt && ADAPT_AT < K) ? ADAPT_AT : K;
   bool need_build = true;
@@ -514,11 +541,11 @@ MPCQP_PHASE void ph_admm(const DevCfg* __restrict__ cfgp, const int adapt) {
       STAMP(3);
       need_build = false;
     }
-    fast_admm_iters<TV>(tile, s, seg_end - it, rho, sigma, relax, mu, stance, fmin, fmax, g3, u3, z5, y5, hv, L.cc, L.second, L.rbM);
+    fast_admm_iters<TV>(tile, s, seg_end - it, rho, sigma, relax, mu, stance, A, L.cc, L.second, L.rbM);
     it = seg_end;
     STAMP(4);
     if (it >= K) break;
-    const float ratio = fast_local_ratio<TV>(s, mu, g3, u3, z5, y5, hv, L.tid);   // early rho check, no gradient call
+    const float ratio = fast_local_ratio<TV>(s, A, L.tid);   // early rho check, no gradient call
     if (ratio > ADAPT_THR) {              // uniform
       rho = fminf(rho * ratio, ADAPT_RHO_MAX);
       need_build = true;
@@ -528,13 +555,8 @@ MPCQP_PHASE void ph_admm(const DevCfg* __restrict__ cfgp, const int adapt) {
     seg_end = K;
     STAMP(5);
   }
-  const float end_ratio = fast_local_ratio<TV>(s, mu, g3, u3, z5, y5, hv, L.tid);   // for the next block's rho, should one be needed
-  if ((L.cc & 3) == 0) {   // publish the iterate
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { s.ua[L.row0 + c] = u3[c]; s.pu[L.row0 + c] = (TV)u3[c]; s.hva[L.row0 + c] = hv[c]; }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { s.za[5 * L.myleg + i] = z5[i]; s.ya[5 * L.myleg + i] = y5[i]; s.py[5 * L.myleg + i] = (TV)y5[i]; }
-  }
+  const float end_ratio = fast_local_ratio<TV>(s, A, L.tid);   // for the next block's rho, should one be needed
+  A.template publish<SmemF<TV>, TV>(s, L.myleg);
   if (L.tid == 0) { s.rho = rho; s.iters += K; s.hard |= hard; s.ratio = end_ratio; }
   __syncthreads();
 }
