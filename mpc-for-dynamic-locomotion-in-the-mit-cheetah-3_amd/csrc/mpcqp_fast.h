@@ -55,7 +55,7 @@ struct SmemF {
   TV pu[120], py[200];
   float ua[120], za[200], ya[200];          // last ADMM iterate (fallback answer, start of the next block)
   float hva[120];                           // H u + g at that iterate, tracked by the iteration
-  float c0[100], c1[100];
+  float c0[100], c1[100];                   // 2 x the stage-pair tables (H = 2 (c1 P.P' + c0 Q.Q'))
   alignas(16) float pq[120 * 12];
   float dg[120];
   alignas(16) float vbuf[2 * FG::VP];
@@ -173,7 +173,7 @@ __device__ __forceinline__ int fast_load_gait(SmemF<TV>& s, const FastIn<TIO>& i
 template <typename TV>
 __device__ __forceinline__ int fast_setup(SmemF<TV>& s, const DevCfg& cfg, const double* __restrict__ ctab, int bad, int tid) {
   constexpr int N = FG::N, n = FG::n, NT = FG::NT;
-  for (int i = tid; i < N * N; i += NT) { s.c0[i] = (float)ctab[i]; s.c1[i] = (float)ctab[N * N + i]; }
+  for (int i = tid; i < N * N; i += NT) { s.c0[i] = (float)(2.0 * ctab[i]); s.c1[i] = (float)(2.0 * ctab[N * N + i]); }   // the factor 2 of H = 2 Su'WSu rides on the tables
   for (int i = tid; i < 2 * FG::VP; i += NT) { s.vbuf[i] = 0.f; s.rhs[i] = 0.f; }   // pad slots must stay finite
   if (tid == 0) {
     s.cf.delta = (TV)cfg.delta; s.cf.theta = (TV)cfg.theta; s.cf.alpha = (TV)cfg.alpha; s.cf.inv_m = (TV)cfg.inv_m;
@@ -216,43 +216,65 @@ __device__ __forceinline__ int fast_setup(SmemF<TV>& s, const DevCfg& cfg, const
   return 0;
 }
 
-// Register tile M[6g..6g+5][15c..15c+14] = 2 (c1 P.P' + c0 Q.Q') + diag, from s.pq / s.dg (two passes of three rows).
+// Register tile M[6g..6g+5][15c..15c+14] = 2 (c1 P.P' + c0 Q.Q') + diag, from s.pq / s.dg.
+// s.pq holds, per variable, the six pairs (P_q, Q_q): one v_pk_fma_f32 then advances both dot products of an entry, the
+// (c1, c0) weights are folded into the column's pairs once per column (the six rows of a thread share one stage), and
+// the diagonal is added after the loop (its position inside the tile depends only on 6g - 15c).
 template <typename TV>
 __device__ __forceinline__ void fast_build(Tile& tile, const SmemF<TV>& s, int grp, int cc) {
   constexpr int N = FG::N;
-  const int col0 = cc * FG::CW;
+  const int col0 = cc * FG::CW, row0 = 6 * grp, stage = row0 / 12;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int r0 = 6 * grp + 3 * h, stage = r0 / 12;
-    float Pr[3][12];
+  for (int h = 0; h < 2; ++h) {   // two passes of three rows: bounds the live registers
+    f2 Pr[3][6];
 #pragma unroll
-    for (int r3 = 0; r3 < 3; ++r3) {
-      const float4* pp = reinterpret_cast<const float4*>(s.pq + (r0 + r3) * 12);
+    for (int r = 0; r < 3; ++r) {
+      const float4* pp = reinterpret_cast<const float4*>(s.pq + (row0 + 3 * h + r) * 12);
 #pragma unroll
-      for (int q4 = 0; q4 < 3; ++q4) { const float4 v = pp[q4]; Pr[r3][4 * q4] = v.x; Pr[r3][4 * q4 + 1] = v.y; Pr[r3][4 * q4 + 2] = v.z; Pr[r3][4 * q4 + 3] = v.w; }
+      for (int q4 = 0; q4 < 3; ++q4) { const float4 v = pp[q4]; Pr[r][2 * q4] = mk2(v.x, v.y); Pr[r][2 * q4 + 1] = mk2(v.z, v.w); }
     }
 #pragma unroll
     for (int c = 0; c < FG::CW; ++c) {
-      if (c % 3 == 0) asm volatile("" ::: "memory");  // at most three columns' loads in flight: bounds the live registers
+      if (c % 3 == 0) asm volatile("" ::: "memory");  // at most three columns' loads in flight
       const int ic = col0 + c, jc = ic / 12;
-      const float k1 = 2.f * s.c1[stage * N + jc], k0 = 2.f * s.c0[stage * N + jc];
-      float pc[12];
+      const float k1 = s.c1[stage * N + jc], k0 = s.c0[stage * N + jc];
+      f2 pc[6];
       const float4* pp = reinterpret_cast<const float4*>(s.pq + ic * 12);
 #pragma unroll
-      for (int q4 = 0; q4 < 3; ++q4) { const float4 v = pp[q4]; pc[4 * q4] = v.x; pc[4 * q4 + 1] = v.y; pc[4 * q4 + 2] = v.z; pc[4 * q4 + 3] = v.w; }
+      for (int q4 = 0; q4 < 3; ++q4) { const float4 v = pp[q4]; pc[2 * q4] = mk2(v.x, v.y); pc[2 * q4 + 1] = mk2(v.z, v.w); }
+      f2 acc[3];   // three independent chains, interleaved (back-to-back dependent packed FMAs cost a wait state each)
 #pragma unroll
-      for (int r3 = 0; r3 < 3; ++r3) {
-        float dp = 0.f, dq = 0.f;
+      for (int r = 0; r < 3; ++r) acc[r] = Pr[r][0] * pc[0];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { dp += Pr[r3][q] * pc[q]; dq += Pr[r3][6 + q] * pc[6 + q]; }
-        float v = k1 * dp + k0 * dq;
-        if (ic == r0 + r3) v += s.dg[ic];
-        if (c % 2 == 0) tile[3 * h + r3][c / 2].x = v; else tile[3 * h + r3][c / 2].y = v;
+      for (int q = 1; q < 6; ++q) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) acc[r] = __builtin_elementwise_fma(Pr[r][q], pc[q], acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float v;   // k1 P.P' + k0 Q.Q' (asm: keeps the SLP vectoriser from re-pairing the two halves across entries)
+        asm("v_mul_f32 %0, %1, %2\n\tv_fmac_f32 %0, %3, %4" : "=&v"(v) : "v"(k0), "v"(acc[r].y), "v"(k1), "v"(acc[r].x));
+        if (c % 2 == 0) tile[3 * h + r][c / 2].x = v; else tile[3 * h + r][c / 2].y = v;
       }
     }
   }
 #pragma unroll
   for (int r = 0; r < 6; ++r) tile[r][7].y = 0.f;
+  // diagonal entries (row r, column d + r) with d = 6g - 15c in {0, 6, 12, -3, 3, 9} when the tile meets the diagonal
+  float dgr[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) dgr[r] = s.dg[row0 + r];
+  const int d = row0 - col0;
+#pragma unroll
+  for (int dd = -3; dd <= 12; dd += 3) {
+    if (d == dd) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int c = dd + r;     // compile-time
+        if (c >= 0 && c < FG::CW) { if (c % 2 == 0) tile[r][c / 2].x += dgr[r]; else tile[r][c / 2].y += dgr[r]; }
+      }
+    }
+  }
 }
 
 // In-register symmetric sweep over the enabled variables: tile <- -M^{-1} (Gauss-Jordan without pivoting, SPD).
@@ -358,7 +380,7 @@ __device__ __forceinline__ void fast_describe(SmemF<TV>& s, int myleg, int a, bo
       dgv = !en ? (TV)1 : (a == 2 ? a2 * ((TV)1 + muv * muv * (TV)((xs != 0) + (ys != 0))) : a2);
     }
 #pragma unroll
-    for (int q = 0; q < 12; ++q) s.pq[(row0 + a) * 12 + q] = en ? (float)pv[q] : 0.f;
+    for (int q = 0; q < 12; ++q) s.pq[(row0 + a) * 12 + (q < 6 ? 2 * q : 2 * (q - 6) + 1)] = en ? (float)pv[q] : 0.f;   // pairs (P_q, Q_q)
     s.dg[row0 + a] = (float)dgv;
   } else {
     s.em[myleg] = (uint8_t)((ex ? 1 : 0) | (ey ? 2 : 0) | (ez ? 4 : 0));

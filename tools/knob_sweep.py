@@ -10,8 +10,11 @@ olib = mpcqp.Library(os.path.join(REPO, "oracle", "libmpcqp_oracle.so"))
 oeng = mpcqp.Engine(olib, olib.default_config(eps_abs=1e-10, eps_rel=1e-10, max_iter=100000, polish_max=30))
 sub = {k: batch[k][:512] for k in ("x0", "r", "contact", "xdes", "mu")}
 ref = oeng.solve_batch_host(sub["x0"], sub["r"], sub["contact"], sub["xdes"], sub["mu"], want_X=False)["u"].reshape(512, -1)
-for ce, rho, pm in itertools.product((40, 50, 60, 80, 100, 130), (1.0, 2.0), (3, 4)):
-    sol = mpcqp.MPCBatch(N=10, precision="mixed", check_every=ce, max_iter=8 * ce, rho=rho, polish_max=pm)
+CES = tuple(int(x) for x in os.environ.get('KNOB_CE', '40,50,60,80,100,130').split(','))
+RHOS = tuple(float(x) for x in os.environ.get('KNOB_RHO', '1.0,2.0').split(','))
+PMS = tuple(int(x) for x in os.environ.get('KNOB_PM', '3,4').split(','))
+for ce, rho, pm in itertools.product(CES, RHOS, PMS):
+    sol = mpcqp.MPCBatch(N=10, precision="mixed", check_every=ce, max_iter=4 * ce, rho=rho, polish_max=pm)
     dev = sol.upload(batch)
     for _ in range(2):
         out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
