@@ -103,50 +103,61 @@ __device__ __forceinline__ void block_max(float (&v)[Q], float* red, int tid) {
 //   p_k     = p_0 + k d v_0 + d^2 sum_{j<k} (k-1-j+theta) a_j + d^2 g (k(k-1)/2 + theta k) e_z
 // with tau_j = sum_i tt_i u_i, a_j = sum_i cm_i u_i e_axis(i) over the variables of stage j
 // (src/mpc.py:86-117 restated; tt_i = I_hat_inv (r x e_axis), src/mpc.py:78,98-107).
+// Every phase is ONE branch-free instruction stream for all lanes: the lane's role only selects array bases, offsets
+// and coefficients, and the (j < k) / (k > j) limits of the prefix sums are zero coefficients, not predicated loads
+// (role branches + predicated iterations serialised one LDS latency per term: 7.9 k cycles per call, 13 % of a solve).
 template <typename SM, typename TV, int N>
 __device__ __forceinline__ void struct_grad(SM& s, int tid) {
+  static_assert(N % 5 == 0, "prefix sums are chunked by five stages");
   constexpr int n = 12 * N;
   const TV d = s.cf.delta, th = s.cf.theta;
-  if (tid < N * 9) {
-    const int j = tid / 9, q = tid % 9;
+  if (tid < N * 9) {   // per-stage wrench: tau_j (q < 3), Rz tau_j (3..5), mass-scaled force sum a_j (6..8)
+    const int j = tid / 9, q = tid % 9, dd = q % 3;
+    // (one LDS base + a per-role element offset: selecting between the member arrays by pointer would lose the LDS
+    //  address space and turn the reads into flat loads)
+    const int roff = q < 3 ? 0 : (q < 6 ? (int)(s.ttr - s.tt) : (int)(s.cm - s.tt));
+    const int stride = q < 6 ? 3 : 1, off = roff + (q < 6 ? dd : 0);
     TV acc = 0;
-    if (q < 3) {
 #pragma unroll
-      for (int i = 0; i < 12; ++i) acc += s.tt[(12 * j + i) * 3 + q] * s.uv[12 * j + i];
-    } else if (q < 6) {
+    for (int i0 = 0; i0 < 12; i0 += 4) {   // four terms' loads in flight at a time (the caller's register tile is live)
+      asm volatile("" ::: "memory");
+      TV a[4], u[4];
 #pragma unroll
-      for (int i = 0; i < 12; ++i) acc += s.ttr[(12 * j + i) * 3 + (q - 3)] * s.uv[12 * j + i];
-    } else {
+      for (int i = 0; i < 4; ++i) { a[i] = s.tt[(12 * j + i0 + i) * stride + off]; u[i] = s.uv[12 * j + i0 + i]; }
 #pragma unroll
-      for (int l = 0; l < 4; ++l) acc += s.cm[12 * j + 3 * l + (q - 6)] * s.uv[12 * j + 3 * l + (q - 6)];
+      for (int i = 0; i < 4; ++i) {
+        const TV m = (q < 6 || (i0 + i) % 3 == dd) ? (TV)1 : (TV)0;   // a_j only collects its own axis
+        acc += (a[i] * m) * u[i];
+      }
     }
     s.wr[tid] = acc;
   }
   __syncthreads();
-  if (tid < N * 12) {
+  if (tid < N * 12) {   // states X_k, k = 1..N: prefix sums of the wrench, weighted by (k-1-j+theta) for angles / position
     const int k = tid / 12 + 1, c = tid % 12, dd = c % 3;
     const TV g = s.x0[12];
+    const bool weighted = c < 6;
+    const int off = c < 3 ? 3 + dd : (c < 6 ? 6 + dd : (c < 9 ? dd : 6 + dd));
+    TV acc = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < N; j0 += 5) {
+      asm volatile("" ::: "memory");
+      TV w[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) w[j] = s.wr[(j0 + j) * 9 + off];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const TV cf = (j0 + j < k) ? (weighted ? (TV)(k - 1 - j0 - j) + th : (TV)1) : (TV)0;
+        acc += cf * w[j];
+      }
+    }
     TV val;
-    if (c < 3) {
-      TV acc = 0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) acc += (j < k) ? ((TV)(k - 1 - j) + th) * s.wr[j * 9 + 3 + dd] : (TV)0;
-      val = s.x0[dd] + (TV)k * d * s.rzw0[dd] + d * d * acc;
-    } else if (c < 6) {
-      TV acc = 0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) acc += (j < k) ? ((TV)(k - 1 - j) + th) * s.wr[j * 9 + 6 + dd] : (TV)0;
+    if (c < 3) val = s.x0[dd] + (TV)k * d * s.rzw0[dd] + d * d * acc;
+    else if (c < 6) {
       val = s.x0[3 + dd] + (TV)k * d * s.x0[9 + dd] + d * d * acc;
       if (dd == 2) val += d * d * g * ((TV)(k * (k - 1)) * (TV)0.5 + th * (TV)k);
-    } else if (c < 9) {
-      TV acc = 0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) acc += (j < k) ? s.wr[j * 9 + dd] : (TV)0;
-      val = s.x0[6 + dd] + d * acc;
-    } else {
-      TV acc = 0;
-#pragma unroll
-      for (int j = 0; j < N; ++j) acc += (j < k) ? s.wr[j * 9 + 6 + dd] : (TV)0;
+    } else if (c < 9) val = s.x0[6 + dd] + d * acc;
+    else {
       val = s.x0[9 + dd] + d * acc;
       if (dd == 2) val += (TV)k * d * g;
     }
@@ -154,29 +165,25 @@ __device__ __forceinline__ void struct_grad(SM& s, int tid) {
     s.es[k * 12 + c] = s.cf.w[c] * (val - s.xd[k * 13 + c]);
   }
   __syncthreads();
-  if (tid < N * 9) {
+  if (tid < N * 9) {   // adjoint of the prefix sums: out = c1 S1 + c2 S2, S1 plain / S2 weighted suffix sums of the errors
     const int j = tid / 9, q = tid % 9, dd = q % 3;
-    TV out;
-    if (q < 3) {
-      TV acc = 0;
+    const int off1 = q < 3 ? 6 + dd : 9 + dd, off2 = q < 6 ? dd : 3 + dd;
+    const TV c1 = (q >= 3 && q < 6) ? (TV)0 : (TV)2 * d, c2 = q < 3 ? (TV)0 : (TV)2 * d * d;
+    TV a1 = 0, a2 = 0;
 #pragma unroll
-      for (int k = 1; k <= N; ++k) acc += (k > j) ? s.es[k * 12 + 6 + dd] : (TV)0;
-      out = (TV)2 * d * acc;
-    } else if (q < 6) {
-      TV acc = 0;
+    for (int k0 = 1; k0 <= N; k0 += 5) {
+      asm volatile("" ::: "memory");
+      TV e1[5], e2[5];
 #pragma unroll
-      for (int k = 1; k <= N; ++k) acc += (k > j) ? ((TV)(k - 1 - j) + th) * s.es[k * 12 + dd] : (TV)0;
-      out = (TV)2 * d * d * acc;
-    } else {
-      TV a1 = 0, a2 = 0;
+      for (int k = 0; k < 5; ++k) { e1[k] = s.es[(k0 + k) * 12 + off1]; e2[k] = s.es[(k0 + k) * 12 + off2]; }
 #pragma unroll
-      for (int k = 1; k <= N; ++k) {
-        a1 += (k > j) ? s.es[k * 12 + 9 + dd] : (TV)0;
-        a2 += (k > j) ? ((TV)(k - 1 - j) + th) * s.es[k * 12 + 3 + dd] : (TV)0;
+      for (int k = 0; k < 5; ++k) {
+        const TV on = (k0 + k > j) ? (TV)1 : (TV)0;
+        a1 += on * e1[k];
+        a2 += (on * ((TV)(k0 + k - 1 - j) + th)) * e2[k];
       }
-      out = (TV)2 * d * a1 + (TV)2 * d * d * a2;
     }
-    s.adj[tid] = out;
+    s.adj[tid] = c1 * a1 + c2 * a2;
   }
   __syncthreads();
   if (tid < n) {
