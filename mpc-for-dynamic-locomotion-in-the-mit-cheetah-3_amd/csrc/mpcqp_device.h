@@ -69,10 +69,17 @@ __device__ __forceinline__ T group8_sum(T v) {
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 
+// Max over the 64 lanes of a full wave: four DPP steps inside each row of 16, then the four row results through
+// v_readlane (a __shfl_xor butterfly is six LDS-latency ds_bpermute round trips).
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
-  return v;
+  v = fmaxf(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_mov<0x141>(v));   // row_half_mirror
+  v = fmaxf(v, dpp_mov<0x140>(v));   // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // Workgroup-wide max of Q floats; every thread gets the result.  NaN-propagating via the isnan flag in slot Q-1

@@ -656,26 +656,28 @@ MPCQP_PHASE int ph_polish_step() {
   ok = false;
   // stage 0: two refinement rounds, then a loose KKT screen; only a plausible candidate is refined to the tight
   // tolerance (stage 1) and checked for real.  Wrong active sets are dropped early.
+  TV gr[3] = {0, 0, 0}, rgv[3] = {0, 0, 0};
   for (int stg = 0; stg < 2; ++stg) {
     const float tol = stg == 0 ? fmaxf(tol_stat, 1e-3f * fmaxf(gmaxf, 1.f)) : tol_stat;
     const int max_rf = stg == 0 ? 2 : 10;
-    TV gr[3] = {0, 0, 0};
     for (int rf = 0;; ++rf) {
-      if ((cc & 3) == 0) {
+      if (!(stg == 1 && rf == 0)) {   // (stage 1 starts from the gradient stage 0 ended with: the candidate has not moved)
+        if ((cc & 3) == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s.uv[row0 + c] = uc[c];
+          for (int c = 0; c < 3; ++c) s.uv[row0 + c] = uc[c];
+        }
+        __syncthreads();
+        struct_grad<SmemF<TV>, TV, N>(s, tid);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gr[c] = s.gv[row0 + c];
+        rgv[0] = ex ? gr[0] : (TV)0; rgv[1] = ey ? gr[1] : (TV)0;
+        rgv[2] = ez ? gr[2] + (TV)xs * muv * gr[0] + (TV)ys * muv * gr[1] : (TV)0;
+        float q[1] = {fmaxf(fmaxf(fabsf((float)rgv[0]), fabsf((float)rgv[1])), fabsf((float)rgv[2]))};
+        if (!isfinite(q[0])) q[0] = INFINITY;
+        block_max<1, NW>(q, s.red, tid);
+        prev_stat = stat;
+        stat = q[0];
       }
-      __syncthreads();
-      struct_grad<SmemF<TV>, TV, N>(s, tid);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) gr[c] = s.gv[row0 + c];
-      const TV rgv[3] = {ex ? gr[0] : (TV)0, ey ? gr[1] : (TV)0,
-                         ez ? gr[2] + (TV)xs * muv * gr[0] + (TV)ys * muv * gr[1] : (TV)0};
-      float q[1] = {fmaxf(fmaxf(fabsf((float)rgv[0]), fabsf((float)rgv[1])), fabsf((float)rgv[2]))};
-      if (!isfinite(q[0])) q[0] = INFINITY;
-      block_max<1, NW>(q, s.red, tid);
-      prev_stat = stat;
-      stat = q[0];
       if (stat <= tol || rf >= max_rf || (rf > 0 && !(stat < 0.5f * prev_stat))) break;  // converged / stagnated (uniform)
       if ((cc & 3) == 0) {
 #pragma unroll
