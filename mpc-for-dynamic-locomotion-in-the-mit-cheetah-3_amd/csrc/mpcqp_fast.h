@@ -284,15 +284,21 @@ __device__ __forceinline__ void fast_sweep(Tile& tile, SmemF<TV>& s, int grp, in
   constexpr int S = FG::S, VP = FG::VP;
   int step = 0;
   for (int kc2 = 0; kc2 < 4; ++kc2) {
+    // enable masks of the ten leg-stages of this pass, fetched together (a dependent LDS read in front of every
+    // leg-stage sat on the critical path: no load can be hoisted above the pivots' barriers)
+    int emv[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) emv[i] = s.em[10 * kc2 + i];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) emv[i] = __builtin_amdgcn_readfirstlane(emv[i]);
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
       const int kc = 2 * kc2 + par;
-      int em = 0;
 #pragma unroll
       for (int c = 0; c < FG::CW; ++c) {
         const int rr = (c + 3 * par) % 6;        // row inside the owner's tile (compile-time after unrolling)
         const int k = FG::CW * kc + c;           // pivot index
-        if (c % 3 == 0) em = s.em[k / 3];        // uniform: enable mask of the pivot's leg-stage
+        const int em = emv[5 * par + c / 3];     // uniform: enable mask of the pivot's leg-stage
         if (!((em >> (c % 3)) & 1)) continue;
         const int og = k / 6;
         float* vb = s.vbuf + (step & 1) * VP;
