@@ -318,21 +318,23 @@ __device__ __forceinline__ void fast_sweep(Tile& tile, SmemF<TV>& s, int grp, in
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) { const float4 v = r4[q4]; vc[2 * q4] = mk2(v.x, v.y); vc[2 * q4 + 1] = mk2(v.z, v.w); }
         }
+        // The owner's pivot row becomes p * row.  Its tile row IS the published row (bit for bit), so the same FMA
+        // does it with the multiplier 1 - p:  row - (1 - p) row = p row  (one select instead of a masked 8-multiply
+        // region; the rounding of 1 - p costs eps |1 - p| / p relative, ~1e-5 only for the rho = 30 ADMM matrices).
+        const float vrr = (grp == og) ? 1.f - p : vr[rr];
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          const f2 m = splat2(-vr[r]);
+          const f2 m = splat2(r == rr ? -vrr : -vr[r]);
 #pragma unroll
           for (int j = 0; j < 8; ++j) tile[r][j] = __builtin_elementwise_fma(m, vc[j], tile[r][j]);
         }
-        if (grp == og) {
-          const f2 p2 = splat2(p);
+        {   // pivot column (selects, not a branch: a divergent region makes the compiler copy tile registers at the join)
+          const bool col = cc == kc;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) tile[rr][j] = vc[j] * p2;
-        }
-        if (cc == kc) {
-#pragma unroll
-          for (int r = 0; r < 6; ++r) { if (c % 2 == 0) tile[r][c / 2].x = vr[r]; else tile[r][c / 2].y = vr[r]; }
-          if (grp == og) { if (c % 2 == 0) tile[rr][c / 2].x = -p; else tile[rr][c / 2].y = -p; }
+          for (int r = 0; r < 6; ++r) {
+            const float v = (r == rr && grp == og) ? -p : vr[r];
+            if (c % 2 == 0) tile[r][c / 2].x = col ? v : tile[r][c / 2].x; else tile[r][c / 2].y = col ? v : tile[r][c / 2].y;
+          }
         }
         ++step;
       }
@@ -340,8 +342,11 @@ __device__ __forceinline__ void fast_sweep(Tile& tile, SmemF<TV>& s, int grp, in
   }
 }
 
-// out[r] = -(tile row r) . x, summed over the 8 lanes of the group (x in the padded LDS layout).
-__device__ __forceinline__ void fast_matvec(const Tile& tile, const float* __restrict__ x, int cc, float (&out)[6]) {
+// out[r] = -(row r of MY leg-stage) . x for r = 0..2, summed over the 8 lanes of the group (x in the padded LDS layout).
+// Reduce-scatter: a lane only needs its own half's three rows, so the first step trades the other half's partial sums
+// with the mirror lane (lane i <-> 7 - i, which sits in the other half and wants exactly those), then a quad butterfly
+// finishes the three values: 15 cross-lane ops instead of the 18 + 3 selects of an all-reduce of six.
+__device__ __forceinline__ void fast_matvec(const Tile& tile, const float* __restrict__ x, int cc, bool second, float (&out)[3]) {
   f2 acc[6];
 #pragma unroll
   for (int r = 0; r < 6; ++r) acc[r] = mk2(0.f, 0.f);
@@ -357,7 +362,13 @@ __device__ __forceinline__ void fast_matvec(const Tile& tile, const float* __res
     }
   }
 #pragma unroll
-  for (int r = 0; r < 6; ++r) out[r] = -group8_sum(acc[r].x + acc[r].y);
+  for (int r = 0; r < 3; ++r) {
+    const float lo = acc[r].x + acc[r].y, hi = acc[3 + r].x + acc[3 + r].y;
+    float t = (second ? hi : lo) + dpp_mov<0x141>(second ? lo : hi);
+    t += dpp_mov<0xB1>(t);
+    t += dpp_mov<0x4E>(t);
+    out[r] = -t;
+  }
 }
 
 // Writes the 12-vectors / diagonal / enable mask of one leg-stage's three variables (lanes a = 0..2 of the leg's
@@ -460,9 +471,9 @@ __device__ __forceinline__ void fast_admm_iters(const Tile& tile, SmemF<TV>& s, 
   __syncthreads();
   int buf = 0;
   for (int it = 0; it < iters; ++it) {
-    float sum[6];
-    fast_matvec(tile, s.rhs + buf * VP, cc, sum);
-    const float t0 = second ? sum[3] : sum[0], t1 = second ? sum[4] : sum[1], utz = second ? sum[5] : sum[2];
+    float sum[3];
+    fast_matvec(tile, s.rhs + buf * VP, cc, second, sum);
+    const float t0 = sum[0], t1 = sum[1], utz = sum[2];
     const float utc = L.q == 0 ? t0 : (L.q == 1 ? t1 : utz);
     const float hq = sten * fmaf(-dd, utc, fmaf(sigma, L.u, L.w));
     L.hv = fmaf(relax, hq, om * L.hv);
@@ -690,11 +701,11 @@ MPCQP_PHASE int ph_polish_step() {
         for (int c = 0; c < 3; ++c) s.rhs[rbM + c] = (float)(-rgv[c]);
       }
       __syncthreads();
-      float sum[6];
-      fast_matvec(tile, s.rhs, cc, sum);
-      v3[0] += (TV)(second ? sum[3] : sum[0]);
-      v3[1] += (TV)(second ? sum[4] : sum[1]);
-      v3[2] += (TV)(second ? sum[5] : sum[2]);
+      float sum[3];
+      fast_matvec(tile, s.rhs, cc, second, sum);
+      v3[0] += (TV)sum[0];
+      v3[1] += (TV)sum[1];
+      v3[2] += (TV)sum[2];
       if (!ex) v3[0] = 0;
       if (!ey) v3[1] = 0;
       if (!ez) v3[2] = 0;
