@@ -467,10 +467,11 @@ __device__ __forceinline__ void fast_admm_iters(const Tile& tile, SmemF<TV>& s, 
   const float dd = L.comp == 2 ? sigma + rho * (1.f + 4.f * mu * mu) : sigma + 2.f * rho;   // diag(sigma I + rho G'G), my component
   const float sten = stance ? 1.f : 0.f;
   L.update_w(rho);
-  if (L.q < 3) s.rhs[rbM + L.comp] = fmaf(sigma, L.u, L.w - L.g);
+  s.rhs[rbM + L.comp] = fmaf(sigma, L.u, L.w - L.g);   // (lane 3 repeats lane 2's store: no divergent region in the loop)
   __syncthreads();
   int buf = 0;
-  for (int it = 0; it < iters; ++it) {
+  const int n_it = __builtin_amdgcn_readfirstlane(iters);   // scalar trip count: plain s_cmp / s_cbranch loop control
+  for (int it = 0; it < n_it; ++it) {
     float sum[3];
     fast_matvec(tile, s.rhs + buf * VP, cc, second, sum);
     const float t0 = sum[0], t1 = sum[1], utz = sum[2];
@@ -494,7 +495,7 @@ __device__ __forceinline__ void fast_admm_iters(const Tile& tile, SmemF<TV>& s, 
     }
     L.update_w(rho);
     buf ^= 1;
-    if (L.q < 3) s.rhs[buf * VP + rbM + L.comp] = fmaf(sigma, L.u, L.w - L.g);
+    s.rhs[buf * VP + rbM + L.comp] = fmaf(sigma, L.u, L.w - L.g);
     __syncthreads();
   }
 }
