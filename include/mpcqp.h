@@ -58,8 +58,13 @@ extern "C" {
 
 /* flags */
 #define MPCQP_FLAG_POLISH 1u     /* active-set polish after ADMM (OSQP's `polish`; the reference leaves it off) */
-#define MPCQP_FLAG_WARM_START 2u /* RESERVED: per-slot (u, z, y) warm start between calls (the reference's is primal-only,
-                                    src/mpc.py:270-271); accepted and ignored by this version -- every call starts cold */
+#define MPCQP_FLAG_WARM_START 2u /* primal warm start, the reference's `opt.set_initial(U, sol.value(U))` (src/mpc.py:270-271):
+                                    u_out is READ as the initial guess [B,N,12] before it is overwritten with the solution
+                                    (so a buffer that is reused from tick to tick seeds every solve with the previous one;
+                                    all zeros = no guess).  The engine first tries active-set polish steps on the guess's own
+                                    active set and falls back to an ADMM block started from the guess.  Same optimum, same
+                                    status / tolerance contract as a cold solve.  Fast path only (N = 10, MIXED / F32,
+                                    polish on); the general kernel and the CPU checker accept the flag and start cold. */
 #define MPCQP_FLAG_GENERAL_KERNEL 4u /* product library: use the single-launch general kernel even where the fast path applies */
 
 /*

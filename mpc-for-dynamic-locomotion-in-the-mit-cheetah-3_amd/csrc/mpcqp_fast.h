@@ -65,7 +65,7 @@ struct SmemF {
   float gmax;                               // |g|_inf
   float rho;                                // current ADMM penalty
   float ratio;                              // OSQP residual ratio at the end of the last ADMM block
-  int iters, psteps, hard;                  // bookkeeping shared by the phases
+  int iters, psteps, hard, warm;            // bookkeeping shared by the phases
   uint8_t ct[40];
   uint8_t em[40];
 };
@@ -110,6 +110,7 @@ template <typename TIO>
 struct FastIn {
   const TIO* x0; const TIO* r; const uint8_t* contact; const TIO* xdes; const TIO* mu;             // tuple form
   const TIO* ref; const TIO* feet0; const TIO* footholds; const int32_t* gait; const uint8_t* feet_id;   // gait form
+  const TIO* u_init;   // MPCQP_FLAG_WARM_START: primal initial guess [B,N,12] (aliases the output buffer), else null
 };
 
 // Tuple form (src/mpc.py:242-255).  Returns the per-thread "non-finite input" flag.
@@ -532,6 +533,56 @@ constexpr int ADAPT_AT = MPCQP_ADAPT_AT;             // iteration of the single 
 constexpr float ADAPT_THR = MPCQP_ADAPT_THR, ADAPT_RHO_MAX = 30.f;
 constexpr int HARD_ITER_FACTOR = MPCQP_HARD_ITER_FACTOR;      // ADMM block length of the QPs that trigger it (x check_every)
 constexpr int HARD_POLISH_FACTOR = 2;    // ... and their polish-step budget (x polish_max)
+#ifndef MPCQP_WARM_POLISH
+#define MPCQP_WARM_POLISH 2
+#endif
+constexpr int WARM_POLISH = MPCQP_WARM_POLISH;   // polish steps tried on a warm-start guess before the first ADMM block
+
+// Warm start (MPCQP_FLAG_WARM_START; the reference seeds every solve with its previous solution, src/mpc.py:270-271,
+// primal only and unshifted).  The guess u0 becomes (a) the start of the primal-dual active-set iteration: constraints
+// that u0 satisfies with equality (to 1e-3) get a unit multiplier of the right sign, so the first polish step works on
+// u0's own active set, and the kernel tries up to WARM_POLISH polish steps BEFORE any ADMM block; (b) the start
+// (u, z = clamp(G u), y = 0) of the ADMM block that follows if those steps fail.  An all-zero guess means "none" (first tick): cold start.
+template <typename TV, typename TIO>
+__device__ __forceinline__ void fast_warm_start(SmemF<TV>& s, const TIO* __restrict__ u0, int tid) {
+  constexpr int n = FG::n, NT = FG::NT;
+  float amax[1] = {0.f};
+  for (int i = tid; i < n; i += NT) {
+    TV v = (TV)u0[i];
+    if (!isfinite(v) || s.ct[i / 3] == 0) v = 0;          // swing feet carry no force (src/mpc.py:138-149)
+    s.uv[i] = v;
+    amax[0] = fmaxf(amax[0], fabsf((float)v));
+  }
+  block_max<1, FG::NW>(amax, s.red, tid);                 // (two barriers: s.uv is visible afterwards)
+  if (!(amax[0] > 0.f)) return;                           // uniform
+  struct_grad<SmemF<TV>, TV, FG::N>(s, tid);              // s.gv = H u0 + g
+  for (int i = tid; i < n; i += NT) { s.pu[i] = s.uv[i]; s.ua[i] = (float)s.uv[i]; s.hva[i] = (float)s.gv[i]; }
+  if (tid < FG::NL) {
+    const int L = tid;
+    const bool stance = s.ct[L] != 0;
+    const TV mu = s.mu, flo = s.cf.fmin, fhi = s.cf.fmax;
+    const TV fx = s.uv[3 * L], fy = s.uv[3 * L + 1], fz = s.uv[3 * L + 2];
+    const TV g[5] = {fz, fx - mu * fz, fx + mu * fz, fy - mu * fz, fy + mu * fz};
+    const TV tb = (TV)1e-3 * fmax(fabs(fz), (TV)1), tf = (TV)1e-3 * fmax(mu * fabs(fz), (TV)1);
+    TV y[5] = {0, 0, 0, 0, 0};
+    float z[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (stance) {
+      // rows that u0 holds with equality get a unit multiplier of the right sign: the first polish step then works on
+      // u0's own active set.  (Multipliers from stationarity at u0 were tried: away from the optimum they are often
+      // wrong-signed and made the active-set iteration longer, tools/warm_study.py.)
+      y[0] = fz >= fhi - tb ? (TV)1 : (fz <= flo + tb ? (TV)-1 : (TV)0);
+      y[1] = g[1] >= -tf ? (TV)1 : (TV)0;  y[2] = g[2] <= tf ? (TV)-1 : (TV)0;     // fx - mu fz <= 0 <= fx + mu fz
+      y[3] = g[3] >= -tf ? (TV)1 : (TV)0;  y[4] = g[4] <= tf ? (TV)-1 : (TV)0;
+      z[0] = (float)(fz < flo ? flo : (fz > fhi ? fhi : fz));
+      z[1] = (float)(g[1] > 0 ? (TV)0 : g[1]);  z[2] = (float)(g[2] < 0 ? (TV)0 : g[2]);
+      z[3] = (float)(g[3] > 0 ? (TV)0 : g[3]);  z[4] = (float)(g[4] < 0 ? (TV)0 : g[4]);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { s.py[5 * L + i] = y[i]; s.za[5 * L + i] = z[i]; s.ya[5 * L + i] = 0.f; }
+  }
+  if (tid == 0) s.warm = 1;
+  __syncthreads();
+}
 
 // ------------------------------------------------------------------------------------------------------ phases
 template <typename TV, typename TIO, bool GAIT>
@@ -544,8 +595,9 @@ MPCQP_PHASE int ph_setup(const DevCfg* __restrict__ cfgp, const double* __restri
   for (int i = tid; i < FG::NL * 5; i += FG::NT) { s.za[i] = 0.f; s.ya[i] = 0.f; s.py[i] = (TV)0; }
   float q[1] = {tid < FG::n ? fabsf((float)s.gl[tid]) : 0.f};
   block_max<1, FG::NW>(q, s.red, tid);
-  if (tid == 0) { s.gmax = q[0]; s.rho = (float)cfgp->rho; s.iters = 0; s.psteps = 0; s.hard = 0; }
+  if (tid == 0) { s.gmax = q[0]; s.rho = (float)cfgp->rho; s.iters = 0; s.psteps = 0; s.hard = 0; s.warm = 0; }
   __syncthreads();
+  if (in.u_init) fast_warm_start<TV, TIO>(s, in.u_init + b * FG::n, tid);
   return 0;
 }
 
@@ -797,8 +849,8 @@ MPCQP_PHASE void ph_output(TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __re
 template <typename TV, typename TIO, bool GAIT>
 __global__ void __launch_bounds__(FG::NT, MPCQP_FAST_WPE)
 mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const FastIn<TIO> in,
-                 TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __restrict__ statusg, int* __restrict__ itersg,
-                 float* __restrict__ resg) {
+                 TIO* ug, TIO* __restrict__ Xg, int* __restrict__ statusg, int* __restrict__ itersg,
+                 float* __restrict__ resg) {   // (ug is not restrict: the warm-start guess is read from the same buffer)
   constexpr int N = FG::N, n = FG::n, NT = FG::NT;
   const size_t b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -814,7 +866,10 @@ mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ cta
   }
   const int max_iter = cfgp->max_iter, polish_max = cfgp->polish_max;
   int ok = 0;
-  for (int round = 0;; ++round) {
+  if (lds<TV>().warm) {   // warm start: the guess's own active set first, no ADMM unless that fails
+    for (int ps = 0; ps < polish_max && ps < WARM_POLISH && !ok; ++ps) ok = ph_polish_step<TV>();
+  }
+  for (int round = 0; !ok; ++round) {
     ph_admm<TV>(cfgp, round == 0 ? 1 : 0);
     SmemF<TV>& s = lds<TV>();
     const int budget = (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;

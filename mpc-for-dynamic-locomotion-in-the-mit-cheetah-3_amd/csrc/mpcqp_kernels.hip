@@ -230,16 +230,17 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
   hipStream_t st = (hipStream_t)stream;
   hipError_t he = hipSuccess;
   const bool fast = fast_path_applies(h);
+  const bool warm = (h->cfg.flags & MPCQP_FLAG_WARM_START) != 0;   // u_out is read as the initial guess first
   he = hipEventRecord(h->ev0, st);
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
   if (B > 0 && fast) {
     if (h->cfg.dtype == MPCQP_DTYPE_F64) {
       const FastIn<double> in = {(const double*)x0, (const double*)r, contact, (const double*)xdes, (const double*)mu,
-                                 nullptr, nullptr, nullptr, nullptr, nullptr};
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const double*)u_out : nullptr};
       he = launch_fast<double, false>(h, B, in, u_out, X_out, status, iters, res, st);
     } else {
       const FastIn<float> in = {(const float*)x0, (const float*)r, contact, (const float*)xdes, (const float*)mu,
-                                nullptr, nullptr, nullptr, nullptr, nullptr};
+                                nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const float*)u_out : nullptr};
       he = launch_fast<float, false>(h, B, in, u_out, X_out, status, iters, res, st);
     }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
@@ -269,16 +270,19 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
   if (!fast_path_applies(h))
     return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: needs N = 10, MIXED or F32 precision, polish, alpha > 0");
   hipStream_t st = (hipStream_t)stream;
+  const bool warm = (h->cfg.flags & MPCQP_FLAG_WARM_START) != 0;
   hipError_t he = hipEventRecord(h->ev0, st);
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
   if (B > 0) {
     if (h->cfg.dtype == MPCQP_DTYPE_F64) {
       const FastIn<double> in = {(const double*)x0, nullptr, nullptr, nullptr, (const double*)mu, (const double*)ref,
-                                 (const double*)feet0, (const double*)footholds, gait, feet_id};
+                                 (const double*)feet0, (const double*)footholds, gait, feet_id,
+                                 warm ? (const double*)u_out : nullptr};
       he = launch_fast<double, true>(h, B, in, u_out, X_out, status, iters, res, st);
     } else {
       const FastIn<float> in = {(const float*)x0, nullptr, nullptr, nullptr, (const float*)mu, (const float*)ref,
-                                (const float*)feet0, (const float*)footholds, gait, feet_id};
+                                (const float*)feet0, (const float*)footholds, gait, feet_id,
+                                warm ? (const float*)u_out : nullptr};
       he = launch_fast<float, true>(h, B, in, u_out, X_out, status, iters, res, st);
     }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);

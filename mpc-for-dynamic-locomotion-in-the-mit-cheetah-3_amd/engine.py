@@ -20,11 +20,17 @@ def _torch():
 class MPCBatch:
     """One engine handle on one GPU.  All tensors live on ``cuda:<device>``; nothing is copied to the host."""
 
-    def __init__(self, N=10, delta=0.03, device=0, io_dtype="f32", precision="mixed", **overrides):
+    def __init__(self, N=10, delta=0.03, device=0, io_dtype="f32", precision="mixed", warm_start=False, **overrides):
+        """``warm_start=True`` sets MPCQP_FLAG_WARM_START: every solve is seeded with the forces already in the output
+        buffer -- the previous solve's solution unless ``u_init`` is passed -- like ``opt.set_initial(U, sol.value(U))``
+        in the reference (src/mpc.py:270-271)."""
         torch = _torch()
         if not torch.cuda.is_available():
             raise _capi.MpcQpError("MPCBatch needs a GPU: the mpcqp engine has no CPU path")
         lib = _capi.product_library()
+        if warm_start:
+            overrides["flags"] = int(overrides.get("flags", _capi.FLAG_POLISH)) | _capi.FLAG_WARM_START
+        self.warm_start = bool(warm_start)
         cfg = lib.default_config(N=N, delta=delta, device=device,
                                  dtype={"f32": _capi.DTYPE_F32, "f64": _capi.DTYPE_F64}[io_dtype],
                                  precision={"f32": _capi.PREC_F32, "mixed": _capi.PREC_MIXED, "f64": _capi.PREC_F64}[precision],
@@ -49,7 +55,7 @@ class MPCBatch:
         if key not in self._out:   # allocated once per batch size, reused afterwards
             N = self.N
             self._out[key] = {
-                "u": torch.empty((B, N, 12), dtype=self.tdtype, device=self.device),
+                "u": torch.zeros((B, N, 12), dtype=self.tdtype, device=self.device),   # zeros = "no guess" for a warm-started engine
                 "X": torch.empty((B, N + 1, 13), dtype=self.tdtype, device=self.device) if want_X else None,
                 "status": torch.empty(B, dtype=torch.int32, device=self.device),
                 "iters": torch.empty(B, dtype=torch.int32, device=self.device),
@@ -57,7 +63,18 @@ class MPCBatch:
             }
         return self._out[key]
 
-    def solve_batch(self, x0, r, contact, xdes, mu, want_X=False, stream=None):
+    def _seed(self, out, u_init, st):
+        if u_init is None:
+            return
+        if not self.warm_start:
+            raise ValueError("u_init needs an engine created with warm_start=True")
+        if tuple(u_init.shape) != tuple(out["u"].shape) or u_init.dtype != self.tdtype or u_init.device != self.device:
+            raise ValueError(f"u_init must be a {tuple(out['u'].shape)} {self.tdtype} tensor on {self.device}")
+        if u_init.data_ptr() != out["u"].data_ptr():
+            with _torch().cuda.stream(st):
+                out["u"].copy_(u_init)
+
+    def solve_batch(self, x0, r, contact, xdes, mu, want_X=False, stream=None, u_init=None):
         """Asynchronous on ``stream`` (default: torch's current stream); results valid after a stream sync."""
         torch = _torch()
         N = self.N
@@ -69,6 +86,7 @@ class MPCBatch:
                                  f"{tuple(t.shape)} {t.dtype} on {t.device}")
         out = self._outputs(B, want_X)
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._seed(out, u_init, st)
         self.engine.solve_batch_ptr(B, x0.data_ptr(), r.data_ptr(), contact.data_ptr(), xdes.data_ptr(), mu.data_ptr(),
                                     out["u"].data_ptr(), out["X"].data_ptr() if want_X else None, out["status"].data_ptr(),
                                     out["iters"].data_ptr(), out["res"].data_ptr(), st.cuda_stream)
@@ -82,7 +100,7 @@ class MPCBatch:
                 "gait": torch.as_tensor(np.ascontiguousarray(g["gait"], dtype=np.int32)).to(self.device).contiguous(),
                 "feet_id": torch.as_tensor(np.ascontiguousarray(g["feet_id"], dtype=np.uint8)).to(self.device).contiguous()}
 
-    def solve_batch_gait(self, x0, ref, feet0, footholds, gait, feet_id, mu, want_X=False, stream=None):
+    def solve_batch_gait(self, x0, ref, feet0, footholds, gait, feet_id, mu, want_X=False, stream=None, u_init=None):
         """Gait entry point: contact masks, stance lever arms and x_des are generated on the device (include/mpcqp.h)."""
         torch = _torch()
         N = self.N
@@ -95,6 +113,7 @@ class MPCBatch:
                                  f"{tuple(t.shape)} {t.dtype} on {t.device}")
         out = self._outputs(B, want_X)
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._seed(out, u_init, st)
         self.engine.solve_batch_gait_ptr(B, x0.data_ptr(), ref.data_ptr(), feet0.data_ptr(), footholds.data_ptr(), gait.data_ptr(),
                                          feet_id.data_ptr(), mu.data_ptr(), out["u"].data_ptr(),
                                          out["X"].data_ptr() if want_X else None, out["status"].data_ptr(),

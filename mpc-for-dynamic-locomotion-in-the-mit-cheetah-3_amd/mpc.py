@@ -96,6 +96,9 @@ class MPC:
 
     def _make_solver(self, device, precision, engine_overrides):
         """The HIP engine.  (tests/ override this hook to drive the same surface with the CPU checker.)"""
+        # warm_start: every solve is seeded with the previous solution, the reference's
+        # `opt.set_initial(U, sol.value(U))` (src/mpc.py:270-271); the engine keeps it in its output buffer
+        engine_overrides.setdefault("warm_start", True)
         return MPCBatch(N=self.N, delta=self.delta, device=device, io_dtype="f64", precision=precision, **engine_overrides)
 
     def _solve_one(self, x0, r, contact, xdes):
@@ -104,7 +107,12 @@ class MPC:
                                    "mu": np.array([float(self.mu)])})
         out = self._solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], want_X=True)
         torch.cuda.synchronize(self._solver.device)
-        return out["u"][0].cpu().numpy(), out["X"][0].cpu().numpy(), int(out["status"][0].item())
+        res = out["u"][0].cpu().numpy(), out["X"][0].cpu().numpy(), int(out["status"][0].item())
+        if getattr(self._solver, "warm_start", False):
+            # next tick's initial guess: this solution moved up by one stage (the horizon step equals the control
+            # tick, src/main.py:32 / src/mpc.py:33); the reference keeps it unshifted -- same optimum either way
+            out["u"][:, :-1] = out["u"][:, 1:].clone()
+        return res
 
     # the reference keeps these on the instance and mutates them every tick
     @property
