@@ -159,7 +159,7 @@ def main():
         hbm = algorithmic_bytes(N) * B / (kernel_ms * 1e-3) / 1e9
         traffic = None     # HBM bytes per launch from the committed PMC passes (tools/pmc_hbm.sh), same workload only
         try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "r01_e_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(REPO, "profiles", "r01_f_hbm_traffic.json")))
             if B == 4096 and args.precision == "mixed":
                 traffic = tj["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
