@@ -66,6 +66,10 @@ extern "C" {
                                     status / tolerance contract as a cold solve.  Fast path only (N = 10, MIXED / F32,
                                     polish on); the general kernel and the CPU checker accept the flag and start cold. */
 #define MPCQP_FLAG_GENERAL_KERNEL 4u /* product library: use the single-launch general kernel even where the fast path applies */
+#define MPCQP_FLAG_NATURAL_ORDER 8u  /* product library: one workgroup per QP in batch order.  By default a batch that
+                                        oversubscribes the device (>= 4 QPs per CU) is solved by resident workgroups that pull
+                                        QPs dearest-expected-first from a queue (a pre-pass ranks the support patterns by
+                                        friction demand): same per-QP results, shorter launch */
 
 /*
  * Problem + solver configuration.  POD, versioned by its leading `size` field (set to sizeof(MpcQpConfig)).

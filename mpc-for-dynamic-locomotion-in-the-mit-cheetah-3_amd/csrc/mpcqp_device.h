@@ -18,6 +18,7 @@ namespace {
 // Never compiled into libmpcqp.so; the values leave through their own buffer and feed no output.
 #ifdef MPCQP_STAMPS
 __device__ unsigned long long g_stamps[32];
+__device__ unsigned long long g_timeline[65536 * 3];   // per QP: start tick, end tick, (xcc << 32 | hw_id): who ran it and when
 #define STAMP_INIT unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_t1;
 #define STAMP(i)                                                       \
   do {                                                                 \

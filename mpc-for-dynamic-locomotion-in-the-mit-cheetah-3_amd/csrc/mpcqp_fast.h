@@ -845,42 +845,143 @@ MPCQP_PHASE void ph_output(TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------------ dispatch order
+// Workgroups are handed out in blockIdx order, and the solve time of a QP varies by 7x (one early rho check, up to four
+// ADMM blocks, 1-8 polish steps): with 4096 QPs on 512 workgroup slots the stragglers that start late set the time of
+// the launch (measured 1.49 ms against 1.0 ms of evenly spread work).  A pre-pass therefore sorts the QPs into
+// ORDER_BUCKETS classes of expected cost and the solve kernel takes the dearest class first.  The predictor is the
+// FRICTION DEMAND of the support pattern: for a stage carried by two feet, the horizontal distance d of the com from
+// the line through the feet over the com height h is the friction coefficient a static stance would need, so
+// (d / h) / mu > 1 means saturated cones, a large active set and slow ADMM convergence (two-legged "amble" support at
+// mu = 0.3: 95 % of those QPs trigger the rho adaptation; diagonal "trot" support: 1 %).  Order only: results are per QP.
+constexpr int ORDER_BUCKETS = 8;
+struct OrderBuf { int* cnt; int* list; int cap; int* head; };   // cnt[ORDER_BUCKETS], list[ORDER_BUCKETS][cap], queue head
+
+__device__ __forceinline__ float support_demand(int nst, const float (&fx)[4], const float (&fy)[4], const float (&fz)[4],
+                                                const bool (&st)[4]) {
+  if (nst == 2) {
+    int a = -1, bidx = -1;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { if (st[l]) { if (a < 0) a = l; else bidx = l; } }
+    const float dx = fx[a] - fx[bidx], dy = fy[a] - fy[bidx];
+    const float d = fabsf(fx[a] * fy[bidx] - fy[a] * fx[bidx]) / fmaxf(sqrtf(dx * dx + dy * dy), 1e-6f);
+    const float h = fmaxf(-0.5f * (fz[a] + fz[bidx]), 1e-3f);
+    return d / h;
+  }
+  if (nst == 1) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) if (st[l]) return sqrtf(fx[l] * fx[l] + fy[l] * fy[l]) / fmaxf(-fz[l], 1e-3f);
+  }
+  return 0.f;   // three or four feet (or flight): no friction-limited moment balance
+}
+
+template <typename TIO, bool GAIT>
+__global__ void __launch_bounds__(256)
+mpcqp_order_kernel(const FastIn<TIO> in, const int B, const OrderBuf ob) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  constexpr int N = FG::N;
+  float score = 0.f;
+  if (!GAIT) {
+    for (int k = 0; k < N; ++k) {
+      float fx[4], fy[4], fz[4]; bool st[4]; int nst = 0;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const TIO* rp = in.r + ((size_t)b * N + k) * 12 + 3 * l;
+        fx[l] = (float)rp[0]; fy[l] = (float)rp[1]; fz[l] = (float)rp[2];
+        st[l] = in.contact[((size_t)b * N + k) * 4 + l] != 0; nst += st[l] ? 1 : 0;
+      }
+      score = fmaxf(score, support_demand(nst, fx, fy, fz, st));
+    }
+  } else {   // the horizon spans at most two steps: their swing patterns on the planned footholds around the reference com
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      float fx[4], fy[4], fz[4]; bool st[4]; int nst = 0;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const TIO* fp = in.footholds + (size_t)b * 24 + sidx * 12 + 3 * l;
+        fx[l] = (float)fp[0] - (float)in.ref[(size_t)b * 10 + 3]; fy[l] = (float)fp[1] - (float)in.ref[(size_t)b * 10 + 4];
+        fz[l] = (float)fp[2] - (float)in.ref[(size_t)b * 10 + 5];
+        st[l] = in.feet_id[(size_t)b * 8 + sidx * 4 + l] != 0; nst += st[l] ? 1 : 0;
+      }
+      score = fmaxf(score, support_demand(nst, fx, fy, fz, st));
+    }
+  }
+  const float mu = fmaxf(fabsf((float)in.mu[b]), 1e-3f);
+  score /= mu;
+  int bucket = isfinite(score) ? (int)fminf(2.f * score, (float)(ORDER_BUCKETS - 1)) : 0;
+  const int pos = atomicAdd(&ob.cnt[bucket], 1);
+  ob.list[(size_t)bucket * ob.cap + pos] = b;
+}
+
 // ------------------------------------------------------------------------------------------------------ the kernel
+// Two launch forms.  Plain: one workgroup per QP, blockIdx = QP.  Queued (ob.list != null, batches that oversubscribe
+// the device): the grid is only as large as the device holds at once (2 workgroups per CU) and every workgroup pulls
+// QPs from the dearest-first order until the queue is empty -- no workgroup turnover between QPs, and the long solves
+// start first.  Every wave leaves the loop when the queue index passes B (bounded by the `guard` count as well).
 template <typename TV, typename TIO, bool GAIT>
 __global__ void __launch_bounds__(FG::NT, MPCQP_FAST_WPE)
 mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const FastIn<TIO> in,
                  TIO* ug, TIO* __restrict__ Xg, int* __restrict__ statusg, int* __restrict__ itersg,
-                 float* __restrict__ resg) {   // (ug is not restrict: the warm-start guess is read from the same buffer)
+                 float* __restrict__ resg, const OrderBuf ob, const int Btot) {   // (ug is not restrict: the warm-start guess is read from the same buffer)
   constexpr int N = FG::N, n = FG::n, NT = FG::NT;
-  const size_t b = blockIdx.x;
+  __shared__ int s_next;
   const int tid = threadIdx.x;
-  if (ph_setup<TV, TIO, GAIT>(cfgp, ctab, in, b)) {   // non-finite input -> zero outputs, status -1
-    for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
-    if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (N + 1) * 13 + i] = (TIO)0;
-    if (tid == 0) {
-      statusg[b] = MPCQP_STATUS_NONFINITE;
-      itersg[b] = 0;
-      if (resg) { resg[2 * b] = 0.f; resg[2 * b + 1] = 0.f; }
+  for (int guard = 0; guard <= Btot; ++guard) {
+    size_t b = blockIdx.x;
+    if (ob.list) {
+      if (tid == 0) s_next = atomicAdd(ob.head, 1);
+      __syncthreads();
+      int i = s_next;
+      __syncthreads();                       // (also fences the previous QP's last LDS reads from the next one's setup)
+      if (i >= Btot) break;                  // uniform
+      for (int k = ORDER_BUCKETS - 1; k >= 0; --k) {   // dearest class first (uniform scalar walk over the class counts)
+        const int c = ob.cnt[k];
+        if (i < c) { b = (size_t)ob.list[(size_t)k * ob.cap + i]; break; }
+        i -= c;
+      }
     }
-    return;
+#ifdef MPCQP_STAMPS
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    if (ph_setup<TV, TIO, GAIT>(cfgp, ctab, in, b)) {   // non-finite input -> zero outputs, status -1
+      for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
+      if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (N + 1) * 13 + i] = (TIO)0;
+      if (tid == 0) {
+        statusg[b] = MPCQP_STATUS_NONFINITE;
+        itersg[b] = 0;
+        if (resg) { resg[2 * b] = 0.f; resg[2 * b + 1] = 0.f; }
+      }
+      if (!ob.list) break;
+      continue;
+    }
+    const int max_iter = cfgp->max_iter, polish_max = cfgp->polish_max;
+    int ok = 0;
+    if (lds<TV>().warm) {   // warm start: the guess's own active set first, no ADMM unless that fails
+      for (int ps = 0; ps < polish_max && ps < WARM_POLISH && !ok; ++ps) ok = ph_polish_step<TV>();
+    }
+    for (int round = 0; !ok; ++round) {
+      ph_admm<TV>(cfgp, round == 0 ? 1 : 0);
+      SmemF<TV>& s = lds<TV>();
+      const int budget = (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
+      for (int ps = 0; ps < budget && !ok; ++ps) ok = ph_polish_step<TV>();
+      if (ok || s.iters >= max_iter) break;
+      // not solved: OSQP's rho adaptation from the residuals of the last ADMM iterate, then another block
+      const float ratio = s.ratio;
+      if (tid == 0 && isfinite(ratio) && (ratio > 2.f || ratio < 0.5f)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
+      __syncthreads();
+    }
+    ph_output<TV, TIO>(ug, Xg, statusg, itersg, resg, b, ok);
+#ifdef MPCQP_STAMPS
+    if (tid == 0 && b < 65536) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_timeline[3 * b] = tl_t0; g_timeline[3 * b + 1] = __builtin_amdgcn_s_memtime();
+      g_timeline[3 * b + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+    if (!ob.list) break;
   }
-  const int max_iter = cfgp->max_iter, polish_max = cfgp->polish_max;
-  int ok = 0;
-  if (lds<TV>().warm) {   // warm start: the guess's own active set first, no ADMM unless that fails
-    for (int ps = 0; ps < polish_max && ps < WARM_POLISH && !ok; ++ps) ok = ph_polish_step<TV>();
-  }
-  for (int round = 0; !ok; ++round) {
-    ph_admm<TV>(cfgp, round == 0 ? 1 : 0);
-    SmemF<TV>& s = lds<TV>();
-    const int budget = (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
-    for (int ps = 0; ps < budget && !ok; ++ps) ok = ph_polish_step<TV>();
-    if (ok || s.iters >= max_iter) break;
-    // not solved: OSQP's rho adaptation from the residuals of the last ADMM iterate, then another block
-    const float ratio = s.ratio;
-    if (tid == 0 && isfinite(ratio) && (ratio > 2.f || ratio < 0.5f)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
-    __syncthreads();
-  }
-  ph_output<TV, TIO>(ug, Xg, statusg, itersg, resg, b, ok);
 }
 
 }  // namespace

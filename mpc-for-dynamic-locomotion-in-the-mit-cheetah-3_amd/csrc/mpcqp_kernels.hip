@@ -51,6 +51,9 @@ struct mpcqp_engine {
   double* ctab = nullptr;   // [2][N][N] coefficient tables on the device
   DevCfg* dcfg = nullptr;   // device copy of `dev`
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int* order_mem = nullptr;   // dispatch order of the fast path: [16 header ints: class counters, queue head | ORDER_BUCKETS x order_cap indices]
+  int order_cap = 0;
+  int slots = 0;              // workgroups the device holds at once (2 per CU)
   bool timed = false;
   char err[512];
 };
@@ -80,15 +83,34 @@ hipError_t launch(const mpcqp_engine* e, int64_t B, const void* x0, const void* 
 #endif
 // Fast path (mpcqp_fast.h): one launch, one QP per workgroup, phases as separately register-allocated device functions.
 template <typename TIO, bool GAIT>
-hipError_t launch_fast(const mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
+hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
                        float* res, hipStream_t s) {
-  const dim3 grid((unsigned)B);
+  dim3 grid((unsigned)B);
+  OrderBuf ob = {nullptr, nullptr, 0, nullptr};
+  // dispatch order (mpcqp_fast.h): worth a pre-pass only when the batch oversubscribes the workgroup slots
+  if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && e->slots > 0 && B >= 2 * (int64_t)e->slots) {
+    if (e->order_cap < B) {   // grows with the largest batch seen; the old buffer may still be in use by queued work
+      int* mem = nullptr;
+      const int64_t cap = ((B + 1023) / 1024) * 1024;
+      if (hipMalloc(&mem, (size_t)(16 + ORDER_BUCKETS * cap) * sizeof(int)) == hipSuccess) {
+        if (e->order_mem) { (void)hipDeviceSynchronize(); (void)hipFree(e->order_mem); }
+        e->order_mem = mem; e->order_cap = (int)cap;
+      }
+    }
+    if (e->order_cap >= B) {
+      ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 16; ob.cap = e->order_cap;
+      hipError_t he = hipMemsetAsync(ob.cnt, 0, 16 * sizeof(int), s);
+      if (he != hipSuccess) return he;
+      hipLaunchKernelGGL((mpcqp_order_kernel<TIO, GAIT>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, in, (int)B, ob);
+      grid = dim3((unsigned)(B < e->slots ? B : e->slots));   // queued form: resident workgroups pull QPs
+    }
+  }
   if (e->cfg.precision == MPCQP_PREC_MIXED)
     hipLaunchKernelGGL((mpcqp_fast_solve<double, TIO, GAIT>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
-                       st, it, res);
+                       st, it, res, ob, (int)B);
   else
     hipLaunchKernelGGL((mpcqp_fast_solve<float, TIO, GAIT>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
-                       st, it, res);
+                       st, it, res, ob, (int)B);
   return hipGetLastError();
 }
 
@@ -165,6 +187,7 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return reject(MPCQP_ENODEV);
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return reject(MPCQP_ENODEV);  // gfx950 code objects only
+  e->slots = 2 * prop.multiProcessorCount;   // the fast path's 256-VGPR, 3-wave workgroups: two per CU
   if (hipSetDevice(cfg->device) != hipSuccess) return reject(MPCQP_EHIP);
 
   DevCfg& d = e->dev;
@@ -213,6 +236,7 @@ int mpcqp_destroy(mpcqp_handle h) {
   if (!h) return MPCQP_OK;
   if (h->ctab) (void)hipFree(h->ctab);
   if (h->dcfg) (void)hipFree(h->dcfg);
+  if (h->order_mem) (void)hipFree(h->order_mem);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   delete h;
@@ -319,6 +343,12 @@ int mpcqp_last_kernel_ms(mpcqp_handle h, float* ms) {
   return MPCQP_OK;
 }
 
+#ifdef MPCQP_STAMPS
+extern "C" int mpcqp_debug_read_timeline(unsigned long long* out, int64_t B) {
+  if (B > 65536) return MPCQP_EINVAL;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)B * 3 * sizeof(unsigned long long)) == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+}
+#endif
 #ifdef MPCQP_STAMPS
 // diagnostic build only: read and reset the phase counters
 int mpcqp_debug_read_stamps(unsigned long long* out32) {

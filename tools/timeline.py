@@ -1,0 +1,45 @@
+"""Diagnostic (stamps build): per-QP start / end ticks and the CU that ran it -> where the launch time goes."""
+import ctypes, os, sys
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import mpcqp
+from mpcqp import _capi
+lib = _capi.Library(os.path.join(REPO, "mpc-for-dynamic-locomotion-in-the-mit-cheetah-3_amd", "csrc", "libmpcqp_stamps.so"))
+_capi._product = lib
+B = 4096
+flags = 1 | (8 if len(sys.argv) > 1 and sys.argv[1] == "natural" else 0)
+batch = mpcqp.synth.config3(B)
+sol = mpcqp.MPCBatch(N=10, precision="mixed", flags=flags)
+dev = sol.upload(batch)
+for _ in range(3):
+    out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * (3 * B))()
+lib.lib.mpcqp_debug_read_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+assert lib.lib.mpcqp_debug_read_timeline(buf, B) == 0
+t = np.array(list(buf), dtype=np.uint64).reshape(B, 3)
+t0 = t[:, 0].astype(np.float64); t1 = t[:, 1].astype(np.float64)
+hw = (t[:, 2] & np.uint64(0xffffffff)).astype(np.int64); xcc = (t[:, 2] >> np.uint64(32)).astype(np.int64) & 0xf
+base = t0.min()
+dur = t1 - t0
+TICK = 2.4e3  # ticks per us (s_memtime runs at 2.4 GHz, tools/ub)
+print(f"kernel {sol.last_kernel_ms():.3f} ms")
+for x in np.unique(xcc):   # tick counters are per XCD: only compare inside one
+    m = xcc == x
+    b0 = t0[m].min()
+    ends = np.sort(t1[m] - b0) / TICK
+    starts = np.sort(t0[m] - b0) / TICK
+    print(f"  xcd {x}: {m.sum()} QPs, work {dur[m].sum() / 64 / TICK:7.1f} us/slot, span {ends[-1]:7.1f} us, 64th start {starts[63]:6.1f} us, last start {starts[-1]:7.1f} us, "
+          f"slots idle at the end: 50% of slots done by {ends[-32]:7.1f} us")
+print(f"per-QP duration us: mean {dur.mean() / TICK:.1f} p50 {np.median(dur) / TICK:.1f} p90 {np.percentile(dur, 90) / TICK:.1f} max {dur.max() / TICK:.1f}; sum/512 = {dur.sum() / 512 / TICK:.1f} us")
+cu = (hw >> 8) & 0xf; se = (hw >> 13) & 0x7; sh = (hw >> 12) & 1
+key = xcc * 1000 + se * 100 + sh * 20 + cu
+ids, inv = np.unique(key, return_inverse=True)
+print(f"distinct CUs seen: {len(ids)}; QPs per CU: min {np.bincount(inv).min()} max {np.bincount(inv).max()}")
+busy = np.array([dur[inv == i].sum() for i in range(len(ids))])
+print(f"per-CU busy (sum of its QP durations / 2 slots) us: mean {busy.mean() / 2 / TICK:.1f} max {busy.max() / 2 / TICK:.1f}; ")
+st = out["iters"].cpu().numpy()
+m = xcc == np.unique(xcc)[0]
+idx = np.nonzero(m)[0]; late = idx[np.argsort(-t1[idx])[:6]]
+print("xcd0 last finishers (end us, duration us, iters):", [(round((t1[i] - t0[m].min()) / TICK), round(dur[i] / TICK), int(st[i])) for i in late])
