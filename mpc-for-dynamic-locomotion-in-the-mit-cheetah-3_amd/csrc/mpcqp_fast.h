@@ -172,16 +172,19 @@ __device__ __forceinline__ int fast_load_gait(SmemF<TV>& s, const FastIn<TIO>& i
 // Stage the constants, build the per-variable response vectors and the linear term g.  Returns the uniform
 // "non-finite input" flag.  Ends with a barrier.
 template <typename TV>
-__device__ __forceinline__ int fast_setup(SmemF<TV>& s, const DevCfg& cfg, const double* __restrict__ ctab, int bad, int tid) {
+__device__ __forceinline__ int fast_setup(SmemF<TV>& s, const DevCfg& cfg, const double* __restrict__ ctab, int bad, int tid,
+                                          bool first) {
   constexpr int N = FG::N, n = FG::n, NT = FG::NT;
-  for (int i = tid; i < N * N; i += NT) { s.c0[i] = (float)(2.0 * ctab[i]); s.c1[i] = (float)(2.0 * ctab[N * N + i]); }   // the factor 2 of H = 2 Su'WSu rides on the tables
-  for (int i = tid; i < 2 * FG::VP; i += NT) { s.vbuf[i] = 0.f; s.rhs[i] = 0.f; }   // pad slots must stay finite
-  if (tid == 0) {
-    s.cf.delta = (TV)cfg.delta; s.cf.theta = (TV)cfg.theta; s.cf.alpha = (TV)cfg.alpha; s.cf.inv_m = (TV)cfg.inv_m;
-    s.cf.fmin = (TV)cfg.fmin; s.cf.fmax = (TV)cfg.fmax;
+  if (first) {   // configuration constants: staged once per workgroup (the queued form solves many QPs with one)
+    for (int i = tid; i < N * N; i += NT) { s.c0[i] = (float)(2.0 * ctab[i]); s.c1[i] = (float)(2.0 * ctab[N * N + i]); }   // the factor 2 of H = 2 Su'WSu rides on the tables
+    if (tid == 0) {
+      s.cf.delta = (TV)cfg.delta; s.cf.theta = (TV)cfg.theta; s.cf.alpha = (TV)cfg.alpha; s.cf.inv_m = (TV)cfg.inv_m;
+      s.cf.fmin = (TV)cfg.fmin; s.cf.fmax = (TV)cfg.fmax;
+    }
+    if (tid >= 64 && tid < 76) { s.cf.w[tid - 64] = (TV)cfg.w[tid - 64]; s.cf.sw[tid - 64] = (TV)cfg.sw[tid - 64]; }
+    if (tid >= 128 && tid < 131) s.cf.Ib[tid - 128] = (TV)cfg.Ib[tid - 128];
   }
-  if (tid >= 64 && tid < 76) { s.cf.w[tid - 64] = (TV)cfg.w[tid - 64]; s.cf.sw[tid - 64] = (TV)cfg.sw[tid - 64]; }
-  if (tid >= 128 && tid < 131) s.cf.Ib[tid - 128] = (TV)cfg.Ib[tid - 128];
+  for (int i = tid; i < 2 * FG::VP; i += NT) { s.vbuf[i] = 0.f; s.rhs[i] = 0.f; }   // pad slots must stay finite
   bad = __syncthreads_or(bad);
   if (bad) return 1;
   if (tid == 0) {
@@ -586,11 +589,15 @@ __device__ __forceinline__ void fast_warm_start(SmemF<TV>& s, const TIO* __restr
 
 // ------------------------------------------------------------------------------------------------------ phases
 template <typename TV, typename TIO, bool GAIT>
-MPCQP_PHASE int ph_setup(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const FastIn<TIO> in, size_t b) {
+MPCQP_PHASE int ph_setup(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const FastIn<TIO> in, size_t b,
+                         const int first) {
   SmemF<TV>& s = lds<TV>();
   const int tid = threadIdx.x;
+  STAMP_INIT
   const int bad = GAIT ? fast_load_gait<TV, TIO>(s, in, *cfgp, b, tid) : fast_load_tuple<TV, TIO>(s, in, b, tid);
-  if (fast_setup<TV>(s, *cfgp, ctab, bad, tid)) return 1;
+  STAMP(13);
+  if (fast_setup<TV>(s, *cfgp, ctab, bad, tid, first != 0)) return 1;
+  STAMP(14);
   for (int i = tid; i < FG::n; i += FG::NT) { s.ua[i] = 0.f; s.pu[i] = (TV)0; s.hva[i] = (float)s.gl[i]; }   // H 0 + g = g
   for (int i = tid; i < FG::NL * 5; i += FG::NT) { s.za[i] = 0.f; s.ya[i] = 0.f; s.py[i] = (TV)0; }
   float q[1] = {tid < FG::n ? fabsf((float)s.gl[tid]) : 0.f};
@@ -598,6 +605,7 @@ MPCQP_PHASE int ph_setup(const DevCfg* __restrict__ cfgp, const double* __restri
   if (tid == 0) { s.gmax = q[0]; s.rho = (float)cfgp->rho; s.iters = 0; s.psteps = 0; s.hard = 0; s.warm = 0; }
   __syncthreads();
   if (in.u_init) fast_warm_start<TV, TIO>(s, in.u_init + b * FG::n, tid);
+  STAMP(0);
   return 0;
 }
 
@@ -822,6 +830,7 @@ MPCQP_PHASE void ph_output(TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __re
   SmemF<TV>& s = lds<TV>();
   const Lane L;
   const int tid = L.tid, row0 = L.row0;
+  STAMP_INIT
   const bool stance = s.ct[L.myleg] != 0;
   if (!ok && (L.cc & 3) == 0) {   // iteration cap: hand back the last ADMM iterate
 #pragma unroll
@@ -843,6 +852,7 @@ MPCQP_PHASE void ph_output(TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __re
     itersg[b] = s.iters + 1000 * s.psteps;
     if (resg) { resg[2 * b] = s.kkt[1]; resg[2 * b + 1] = fmaxf(s.kkt[2], s.kkt[0]); }
   }
+  STAMP(8);
 }
 
 // ------------------------------------------------------------------------------------------------------ dispatch order
@@ -875,42 +885,52 @@ __device__ __forceinline__ float support_demand(int nst, const float (&fx)[4], c
   return 0.f;   // three or four feet (or flight): no friction-limited moment balance
 }
 
+// 16 lanes per QP, one stage (or one planned step) per lane: the loads of a QP go out together, a DPP row reduction
+// takes the maximum, lane 0 files the QP.
+// The class counters are bumped once per workgroup of 64 QPs (a global atomic per QP on eight addresses serialises).
 template <typename TIO, bool GAIT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 mpcqp_order_kernel(const FastIn<TIO> in, const int B, const OrderBuf ob) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
   constexpr int N = FG::N;
+  __shared__ int lcnt[ORDER_BUCKETS], lbase[ORDER_BUCKETS];
+  if (threadIdx.x < ORDER_BUCKETS) lcnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int b = blockIdx.x * 64 + (threadIdx.x >> 4), k = threadIdx.x & 15;
   float score = 0.f;
-  if (!GAIT) {
-    for (int k = 0; k < N; ++k) {
-      float fx[4], fy[4], fz[4]; bool st[4]; int nst = 0;
+  if (b < B && k < (GAIT ? 2 : N)) {
+    float fx[4], fy[4], fz[4]; bool st[4]; int nst = 0;
 #pragma unroll
-      for (int l = 0; l < 4; ++l) {
+    for (int l = 0; l < 4; ++l) {
+      if (!GAIT) {
         const TIO* rp = in.r + ((size_t)b * N + k) * 12 + 3 * l;
         fx[l] = (float)rp[0]; fy[l] = (float)rp[1]; fz[l] = (float)rp[2];
-        st[l] = in.contact[((size_t)b * N + k) * 4 + l] != 0; nst += st[l] ? 1 : 0;
-      }
-      score = fmaxf(score, support_demand(nst, fx, fy, fz, st));
-    }
-  } else {   // the horizon spans at most two steps: their swing patterns on the planned footholds around the reference com
-    for (int sidx = 0; sidx < 2; ++sidx) {
-      float fx[4], fy[4], fz[4]; bool st[4]; int nst = 0;
-#pragma unroll
-      for (int l = 0; l < 4; ++l) {
-        const TIO* fp = in.footholds + (size_t)b * 24 + sidx * 12 + 3 * l;
+        st[l] = in.contact[((size_t)b * N + k) * 4 + l] != 0;
+      } else {   // the horizon spans at most two steps: their swing patterns on the planned footholds around the reference com
+        const TIO* fp = in.footholds + (size_t)b * 24 + k * 12 + 3 * l;
         fx[l] = (float)fp[0] - (float)in.ref[(size_t)b * 10 + 3]; fy[l] = (float)fp[1] - (float)in.ref[(size_t)b * 10 + 4];
         fz[l] = (float)fp[2] - (float)in.ref[(size_t)b * 10 + 5];
-        st[l] = in.feet_id[(size_t)b * 8 + sidx * 4 + l] != 0; nst += st[l] ? 1 : 0;
+        st[l] = in.feet_id[(size_t)b * 8 + k * 4 + l] != 0;
       }
-      score = fmaxf(score, support_demand(nst, fx, fy, fz, st));
+      nst += st[l] ? 1 : 0;
     }
+    score = support_demand(nst, fx, fy, fz, st);
+    if (!isfinite(score)) score = 0.f;
   }
-  const float mu = fmaxf(fabsf((float)in.mu[b]), 1e-3f);
-  score /= mu;
-  int bucket = isfinite(score) ? (int)fminf(2.f * score, (float)(ORDER_BUCKETS - 1)) : 0;
-  const int pos = atomicAdd(&ob.cnt[bucket], 1);
-  ob.list[(size_t)bucket * ob.cap + pos] = b;
+  score = fmaxf(score, dpp_mov<0xB1>(score));    // max over the row of 16 lanes (all lanes of the wave are active here)
+  score = fmaxf(score, dpp_mov<0x4E>(score));
+  score = fmaxf(score, dpp_mov<0x141>(score));
+  score = fmaxf(score, dpp_mov<0x140>(score));
+  int bucket = 0, pos = 0;
+  const bool filer = b < B && k == 0;
+  if (filer) {
+    score /= fmaxf(fabsf((float)in.mu[b]), 1e-3f);
+    bucket = isfinite(score) ? (int)fminf(2.f * score, (float)(ORDER_BUCKETS - 1)) : 0;
+    pos = atomicAdd(&lcnt[bucket], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < ORDER_BUCKETS) lbase[threadIdx.x] = lcnt[threadIdx.x] ? atomicAdd(&ob.cnt[threadIdx.x], lcnt[threadIdx.x]) : 0;
+  __syncthreads();
+  if (filer) ob.list[(size_t)bucket * ob.cap + lbase[bucket] + pos] = b;
 }
 
 // ------------------------------------------------------------------------------------------------------ the kernel
@@ -943,7 +963,7 @@ mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ cta
 #ifdef MPCQP_STAMPS
     const unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (ph_setup<TV, TIO, GAIT>(cfgp, ctab, in, b)) {   // non-finite input -> zero outputs, status -1
+    if (ph_setup<TV, TIO, GAIT>(cfgp, ctab, in, b, guard == 0 ? 1 : 0)) {   // non-finite input -> zero outputs, status -1
       for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
       if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (N + 1) * 13 + i] = (TIO)0;
       if (tid == 0) {

@@ -101,7 +101,7 @@ hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* 
       ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 16; ob.cap = e->order_cap;
       hipError_t he = hipMemsetAsync(ob.cnt, 0, 16 * sizeof(int), s);
       if (he != hipSuccess) return he;
-      hipLaunchKernelGGL((mpcqp_order_kernel<TIO, GAIT>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, in, (int)B, ob);
+      hipLaunchKernelGGL((mpcqp_order_kernel<TIO, GAIT>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
       grid = dim3((unsigned)(B < e->slots ? B : e->slots));   // queued form: resident workgroups pull QPs
     }
   }

@@ -15,7 +15,8 @@ for p in sorted(glob.glob("$OUT/pass*/*/*counter_collection.csv")):
     acc = collections.defaultdict(list)
     for row in csv.DictReader(open(p)):
         if "mpcqp_" in row["Kernel_Name"]:
-            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-    for k, v in acc.items():
-        print(f"{k:16s} per-dispatch mean {sum(v)/len(v):16.1f}  (n={len(v)})")
+            kn = "order" if "order_kernel" in row["Kernel_Name"] else "solve"
+            acc[(kn, row["Counter_Name"])].append(float(row["Counter_Value"]))
+    for k, v in sorted(acc.items()):
+        print(f"{k[0]:6s} {k[1]:16s} per-dispatch mean {sum(v)/len(v):16.1f}  (n={len(v)})")
 PY

@@ -14,14 +14,15 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 batch = mpcqp.synth.config3(B) if N == 10 else mpcqp.synth.config5(B)
 sol = mpcqp.MPCBatch(N=N, precision=prec)
 dev = sol.upload(batch)
-names = ["setup", "matrix-desc", "build", "sweep", "admm-iters", "checkpoint", "polish-refine", "polish-kkt", "output"]
+names = ["setup-rest", "matrix-desc", "build", "sweep", "admm-iters", "checkpoint", "polish-refine", "polish-kkt", "output",
+         "-", "-", "-", "-", "setup-load", "setup-model+g"]
 buf = (ctypes.c_ulonglong * 32)()
 for rep in range(2):
     sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
     torch.cuda.synchronize()
     lib.lib.mpcqp_debug_read_stamps(buf)
 v = np.array(list(buf), dtype=np.float64)
-tot = v[:9].sum()
+tot = v[:16].sum()
 print(f"B={B} prec={prec} N={N} kernel {sol.last_kernel_ms():.3f} ms; cycles/QP total {tot / B:.0f}")
 for i, nme in enumerate(names):
     print(f"  {nme:14s} share {v[i] / tot:6.1%}  cycles/QP {v[i] / B:9.0f}  events/QP {v[16 + i] / B:6.2f}  cycles/event {v[i] / max(v[16 + i], 1):8.0f}")
