@@ -159,7 +159,7 @@ def main():
         hbm = algorithmic_bytes(N) * B / (kernel_ms * 1e-3) / 1e9
         traffic = None     # HBM bytes per launch from the committed PMC passes (tools/pmc_hbm.sh), same workload only
         try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "r01_f_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(REPO, "profiles", "r01_h_hbm_traffic.json")))
             if B == 4096 and args.precision == "mixed":
                 traffic = tj["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
@@ -177,7 +177,7 @@ def main():
                        "solved_fraction": solved, "admm_iters_mean": k_mean, "polish_steps_mean": float((iters // 1000).mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "mpcqp_fast_solve<double,float> (one launch per solve_batch)" if args.precision == "mixed"
+                         "kernel": "mpcqp_fast_solve<double,float> (one launch per solve_batch, after a 5 us ordering pre-pass; both inside kernel_ms)" if args.precision == "mixed"
                          else "mpcqp_fast_solve<float,float>" if args.precision == "f32" else "mpcqp_solve_kernel<double,double,float,10>",
                          "kernel_ms": kernel_ms, "kernel_ms_last_launch": last_ms,
                          "algorithmic_flops_per_qp": flops,

@@ -16,7 +16,7 @@ import csv, glob, collections
 for p in sorted(glob.glob("$OUT/pass*/*/*counter_collection.csv")):
     acc = collections.defaultdict(list)
     for row in csv.DictReader(open(p)):
-        if "mpcqp_" in row["Kernel_Name"]:
+        if "mpcqp_" in row["Kernel_Name"] and "order_kernel" not in row["Kernel_Name"]:   # the solve kernel only
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in acc.items():
         print(f"{k:28s} per-dispatch mean {sum(v)/len(v):16.0f}  (n={len(v)})")

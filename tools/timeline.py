@@ -40,6 +40,7 @@ print(f"distinct CUs seen: {len(ids)}; QPs per CU: min {np.bincount(inv).min()} 
 busy = np.array([dur[inv == i].sum() for i in range(len(ids))])
 print(f"per-CU busy (sum of its QP durations / 2 slots) us: mean {busy.mean() / 2 / TICK:.1f} max {busy.max() / 2 / TICK:.1f}; ")
 st = out["iters"].cpu().numpy()
+np.save(os.path.join(REPO, "gpurun_out", "timeline_dur_us.npy"), dur / TICK)
 m = xcc == np.unique(xcc)[0]
 idx = np.nonzero(m)[0]; late = idx[np.argsort(-t1[idx])[:6]]
 print("xcd0 last finishers (end us, duration us, iters):", [(round((t1[i] - t0[m].min()) / TICK), round(dur[i] / TICK), int(st[i])) for i in late])
