@@ -257,3 +257,28 @@ def test_regulariser_sweep(oracle_solve, alpha, precision, min_solved):
     ok = solved(out["status"])
     assert ok.mean() >= min_solved, ok.mean()
     assert rel_err(out["u"], ref["u"])[ok].max() <= 1e-4
+
+
+def test_queued_form_matches_plain_form_bitwise():
+    """Batches that oversubscribe the device run in the queued form (resident workgroups pulling QPs
+    dearest-expected-first).  It must be a pure re-ordering: outputs bitwise those of the plain
+    one-workgroup-per-QP form (MPCQP_FLAG_NATURAL_ORDER), non-finite QPs included, for both entry points."""
+    B = 1100                                                   # just above the switch-over (4 QPs per CU on 256 CUs)
+    b = mpcqp.synth.config3(B)
+    b["x0"] = b["x0"].copy()
+    b["x0"][[5, 700, 1099], 3] = np.nan                        # non-finite inputs: status -1, zero outputs, the queue moves on
+    plain = gpu_solve(b, io="f32", precision="mixed", flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NATURAL_ORDER)
+    queued = gpu_solve(b, io="f32", precision="mixed")
+    for k in ("u", "X", "status", "iters", "res"):
+        assert np.array_equal(plain[k], queued[k], equal_nan=True), k
+    assert np.all(queued["status"][[5, 700, 1099]] == -1) and solved(np.delete(queued["status"], [5, 700, 1099])).mean() >= 0.97
+    g = mpcqp.synth.make_gait_batch(B)
+    outs = []
+    for flags in (mpcqp.FLAG_POLISH | mpcqp.FLAG_NATURAL_ORDER, mpcqp.FLAG_POLISH):
+        sol = mpcqp.MPCBatch(N=10, io_dtype="f32", precision="mixed", flags=flags)
+        dev = sol.upload_gait(g)
+        o = sol.solve_batch_gait(dev["x0"], dev["ref"], dev["feet0"], dev["footholds"], dev["gait"], dev["feet_id"], dev["mu"])
+        torch.cuda.synchronize()
+        outs.append({k: v.cpu().numpy().copy() for k, v in o.items() if v is not None})
+    for k in ("u", "status", "iters"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
