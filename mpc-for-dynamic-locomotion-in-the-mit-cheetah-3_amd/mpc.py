@@ -96,9 +96,10 @@ class MPC:
 
     def _make_solver(self, device, precision, engine_overrides):
         """The HIP engine.  (tests/ override this hook to drive the same surface with the CPU checker.)"""
-        # warm_start: every solve is seeded with the previous solution, the reference's
-        # `opt.set_initial(U, sol.value(U))` (src/mpc.py:270-271); the engine keeps it in its output buffer
-        engine_overrides.setdefault("warm_start", True)
+        # The reference seeds every solve with the previous solution (`opt.set_initial(U, sol.value(U))`,
+        # src/mpc.py:270-271).  Pass warm_start=True for the same behaviour (MPCQP_FLAG_WARM_START; the guess is moved
+        # up by one stage below).  Off by default: the optimum is the same and, measured, a one-tick-old guess does not
+        # shorten the solve (DESIGN.md, "Warm start").
         return MPCBatch(N=self.N, delta=self.delta, device=device, io_dtype="f64", precision=precision, **engine_overrides)
 
     def _solve_one(self, x0, r, contact, xdes):
