@@ -62,9 +62,13 @@ extern "C" {
                                     u_out is READ as the initial guess [B,N,12] before it is overwritten with the solution
                                     (so a buffer that is reused from tick to tick seeds every solve with the previous one;
                                     all zeros = no guess).  The engine first tries active-set polish steps on the guess's own
-                                    active set and falls back to an ADMM block started from the guess.  Same optimum, same
+                                    active set and falls back to an ADMM block started from the guess.  The engine also keeps,
+                                    per batch slot, the multipliers of its previous solve and starts from those when it has
+                                    them (slot b of consecutive calls = the same robot).  Same optimum, same
                                     status / tolerance contract as a cold solve.  Fast path only (N = 10, MIXED / F32,
                                     polish on); the general kernel and the CPU checker accept the flag and start cold. */
+#define MPCQP_FLAG_WARM_SHIFT 16u    /* with WARM_START: the guess is the PREVIOUS control tick's solution, left in u_out unshifted as the
+                                        reference leaves it; the engine uses its stage k + 1 for stage k (last stage repeated) */
 #define MPCQP_FLAG_GENERAL_KERNEL 4u /* product library: use the single-launch general kernel even where the fast path applies */
 #define MPCQP_FLAG_NATURAL_ORDER 8u  /* product library: one workgroup per QP in batch order.  By default a batch that
                                         oversubscribes the device (>= 4 QPs per CU) is solved by resident workgroups that pull

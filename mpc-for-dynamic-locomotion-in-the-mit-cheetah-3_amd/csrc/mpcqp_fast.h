@@ -111,6 +111,8 @@ struct FastIn {
   const TIO* x0; const TIO* r; const uint8_t* contact; const TIO* xdes; const TIO* mu;             // tuple form
   const TIO* ref; const TIO* feet0; const TIO* footholds; const int32_t* gait; const uint8_t* feet_id;   // gait form
   const TIO* u_init;   // MPCQP_FLAG_WARM_START: primal initial guess [B,N,12] (aliases the output buffer), else null
+  float* y_state;      // ... and the engine's per-slot record of the previous solve's multipliers [cap][40][5] (read, then rewritten)
+  int shift;           // MPCQP_FLAG_WARM_SHIFT: the guess and the record are one control tick old: use stage k + 1 for stage k
 };
 
 // Tuple form (src/mpc.py:242-255).  Returns the per-thread "non-finite input" flag.
@@ -540,6 +542,11 @@ constexpr int HARD_POLISH_FACTOR = 2;    // ... and their polish-step budget (x 
 #define MPCQP_WARM_POLISH 2
 #endif
 constexpr int WARM_POLISH = MPCQP_WARM_POLISH;   // polish steps tried on a warm-start guess before the first ADMM block
+#ifndef MPCQP_WARM_K
+#define MPCQP_WARM_K 60
+#endif
+constexpr int WARM_K = MPCQP_WARM_K;             // length of the first ADMM block when it starts from remembered (u, y)
+constexpr float WARM_KKT_TOL = 1e-3f;            // (u0, y0) counts as a KKT point when its stationarity residual is below this x |g|
 
 // Warm start (MPCQP_FLAG_WARM_START; the reference seeds every solve with its previous solution, src/mpc.py:270-271,
 // primal only and unshifted).  The guess u0 becomes (a) the start of the primal-dual active-set iteration: constraints
@@ -547,17 +554,34 @@ constexpr int WARM_POLISH = MPCQP_WARM_POLISH;   // polish steps tried on a warm
 // u0's own active set, and the kernel tries up to WARM_POLISH polish steps BEFORE any ADMM block; (b) the start
 // (u, z = clamp(G u), y = 0) of the ADMM block that follows if those steps fail.  An all-zero guess means "none" (first tick): cold start.
 template <typename TV, typename TIO>
-__device__ __forceinline__ void fast_warm_start(SmemF<TV>& s, const TIO* __restrict__ u0, int tid) {
-  constexpr int n = FG::n, NT = FG::NT;
-  float amax[1] = {0.f};
+__device__ __forceinline__ void fast_warm_start(SmemF<TV>& s, const TIO* __restrict__ u0, const float* __restrict__ y0,
+                                                const int shift, int tid) {
+  constexpr int n = FG::n, NT = FG::NT, N = FG::N;
+  float amax[2] = {0.f, 0.f};
   for (int i = tid; i < n; i += NT) {
-    TV v = (TV)u0[i];
+    const int k = min(i / 12 + shift, N - 1);
+    TV v = (TV)u0[k * 12 + i % 12];
     if (!isfinite(v) || s.ct[i / 3] == 0) v = 0;          // swing feet carry no force (src/mpc.py:138-149)
     s.uv[i] = v;
     amax[0] = fmaxf(amax[0], fabsf((float)v));
   }
-  block_max<1, FG::NW>(amax, s.red, tid);                 // (two barriers: s.uv is visible afterwards)
-  if (!(amax[0] > 0.f)) return;                           // uniform
+  for (int i = tid; i < FG::NL * 5; i += NT) {            // the previous solve's multipliers, if the engine has them
+    float y = 0.f;
+    if (y0) {
+      const int L = i / 5, k = min(L / 4 + shift, N - 1);
+      y = y0[(k * 4 + L % 4) * 5 + i % 5];
+      if (!isfinite(y) || s.ct[L] == 0) y = 0.f;
+    }
+    s.ya[i] = y;
+    amax[1] = fmaxf(amax[1], fabsf(y));
+  }
+  block_max<2, FG::NW>(amax, s.red, tid);                 // (two barriers: s.uv / s.ya are visible afterwards)
+  if (!(amax[0] > 0.f)) {                                 // uniform: no guess
+    for (int i = tid; i < FG::NL * 5; i += NT) s.ya[i] = 0.f;
+    __syncthreads();
+    return;
+  }
+  const bool duals = amax[1] > 0.f;
   struct_grad<SmemF<TV>, TV, FG::N>(s, tid);              // s.gv = H u0 + g
   for (int i = tid; i < n; i += NT) { s.pu[i] = s.uv[i]; s.ua[i] = (float)s.uv[i]; s.hva[i] = (float)s.gv[i]; }
   if (tid < FG::NL) {
@@ -570,20 +594,37 @@ __device__ __forceinline__ void fast_warm_start(SmemF<TV>& s, const TIO* __restr
     TV y[5] = {0, 0, 0, 0, 0};
     float z[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (stance) {
-      // rows that u0 holds with equality get a unit multiplier of the right sign: the first polish step then works on
-      // u0's own active set.  (Multipliers from stationarity at u0 were tried: away from the optimum they are often
-      // wrong-signed and made the active-set iteration longer, tools/warm_study.py.)
-      y[0] = fz >= fhi - tb ? (TV)1 : (fz <= flo + tb ? (TV)-1 : (TV)0);
-      y[1] = g[1] >= -tf ? (TV)1 : (TV)0;  y[2] = g[2] <= tf ? (TV)-1 : (TV)0;     // fx - mu fz <= 0 <= fx + mu fz
-      y[3] = g[3] >= -tf ? (TV)1 : (TV)0;  y[4] = g[4] <= tf ? (TV)-1 : (TV)0;
+      if (duals) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) y[i] = (TV)s.ya[5 * L + i];
+      } else {
+        // rows that u0 holds with equality get a unit multiplier of the right sign: the first polish step then works on
+        // u0's own active set.  (Multipliers from stationarity at u0 were tried: away from the optimum they are often
+        // wrong-signed and made the active-set iteration longer, tools/warm_study.py.)
+        y[0] = fz >= fhi - tb ? (TV)1 : (fz <= flo + tb ? (TV)-1 : (TV)0);
+        y[1] = g[1] >= -tf ? (TV)1 : (TV)0;  y[2] = g[2] <= tf ? (TV)-1 : (TV)0;     // fx - mu fz <= 0 <= fx + mu fz
+        y[3] = g[3] >= -tf ? (TV)1 : (TV)0;  y[4] = g[4] <= tf ? (TV)-1 : (TV)0;
+      }
       z[0] = (float)(fz < flo ? flo : (fz > fhi ? fhi : fz));
       z[1] = (float)(g[1] > 0 ? (TV)0 : g[1]);  z[2] = (float)(g[2] < 0 ? (TV)0 : g[2]);
       z[3] = (float)(g[3] > 0 ? (TV)0 : g[3]);  z[4] = (float)(g[4] < 0 ? (TV)0 : g[4]);
     }
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { s.py[5 * L + i] = y[i]; s.za[5 * L + i] = z[i]; s.ya[5 * L + i] = 0.f; }
+    for (int i = 0; i < 5; ++i) { s.py[5 * L + i] = y[i]; s.za[5 * L + i] = z[i]; if (!duals) s.ya[5 * L + i] = 0.f; }
   }
-  if (tid == 0) s.warm = 1;
+  // How good is (u0, y0)?  Its stationarity residual |H u0 + g + G'y0| says whether it is (nearly) a KKT point -- then an
+  // active-set step on it is worth trying first -- or only a neighbour, in which case a short ADMM block from it comes first.
+  float rs[1] = {0.f};
+  if (duals && tid < FG::NL && s.ct[tid] != 0) {
+    const int L = tid;
+    const float mu = (float)s.mu;
+    const float y0_ = s.ya[5 * L], y1 = s.ya[5 * L + 1], y2 = s.ya[5 * L + 2], y3 = s.ya[5 * L + 3], y4 = s.ya[5 * L + 4];
+    const float rx = (float)s.gv[3 * L] + y1 + y2, ry = (float)s.gv[3 * L + 1] + y3 + y4;
+    const float rz = (float)s.gv[3 * L + 2] + y0_ + mu * (-y1 + y2 - y3 + y4);
+    rs[0] = fmaxf(fmaxf(fabsf(rx), fabsf(ry)), fabsf(rz));
+  }
+  block_max<1, FG::NW>(rs, s.red, tid);
+  if (tid == 0) s.warm = !duals ? 1 : (rs[0] <= WARM_KKT_TOL * fmaxf(s.gmax, 1.f) ? 2 : 3);
   __syncthreads();
 }
 
@@ -604,7 +645,7 @@ MPCQP_PHASE int ph_setup(const DevCfg* __restrict__ cfgp, const double* __restri
   block_max<1, FG::NW>(q, s.red, tid);
   if (tid == 0) { s.gmax = q[0]; s.rho = (float)cfgp->rho; s.iters = 0; s.psteps = 0; s.hard = 0; s.warm = 0; }
   __syncthreads();
-  if (in.u_init) fast_warm_start<TV, TIO>(s, in.u_init + b * FG::n, tid);
+  if (in.u_init) fast_warm_start<TV, TIO>(s, in.u_init + b * FG::n, in.y_state ? in.y_state + b * (FG::NL * 5) : nullptr, in.shift, tid);
   STAMP(0);
   return 0;
 }
@@ -613,7 +654,7 @@ MPCQP_PHASE int ph_setup(const DevCfg* __restrict__ cfgp, const double* __restri
 // `adapt`: run the single early rho check (round 0 only); a QP that triggers it gets rho <- rho * ratio, a rebuilt
 // matrix and a longer block.  Updates s.rho / s.iters / s.hard and leaves the new iterate in s.ua/za/ya and s.pu/py.
 template <typename TV>
-MPCQP_PHASE void ph_admm(const DevCfg* __restrict__ cfgp, const int adapt) {
+MPCQP_PHASE void ph_admm(const DevCfg* __restrict__ cfgp, const int adapt, const int kfirst) {
   SmemF<TV>& s = lds<TV>();
   const DevCfg& cfg = *cfgp;
   const Lane L;
@@ -623,7 +664,7 @@ MPCQP_PHASE void ph_admm(const DevCfg* __restrict__ cfgp, const int adapt) {
   float rho = s.rho;
   LegLane A(L.cc, stance, mu, fmin, fmax);
   A.load(s, L.myleg);
-  int K = cfg.check_every;
+  int K = kfirst > 0 ? min(kfirst, cfg.check_every) : cfg.check_every;
   int it = 0, seg_end = (adapt && ADAPT_AT < K) ? ADAPT_AT : K;
   bool need_build = true;
   int hard = 0;
@@ -825,7 +866,7 @@ MPCQP_PHASE int ph_polish_step() {
 
 template <typename TV, typename TIO>
 MPCQP_PHASE void ph_output(TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __restrict__ statusg, int* __restrict__ itersg,
-                           float* __restrict__ resg, const size_t b, const int ok) {
+                           float* __restrict__ resg, float* __restrict__ y_state, const size_t b, const int ok) {
   constexpr int N = FG::N, n = FG::n, NT = FG::NT;
   SmemF<TV>& s = lds<TV>();
   const Lane L;
@@ -839,6 +880,9 @@ MPCQP_PHASE void ph_output(TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __re
   if ((L.cc & 3) == 0 && !stance) s.uv[row0] = s.uv[row0 + 1] = s.uv[row0 + 2] = 0;
   __syncthreads();
   for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)s.uv[i];   // src/mpc.py:267-268
+  if (y_state) {   // warm-started engines remember the multipliers of this slot for the next call
+    for (int i = tid; i < FG::NL * 5; i += NT) y_state[b * (FG::NL * 5) + i] = ok ? (float)s.py[i] : s.ya[i];
+  }
   if (Xg) {                                                          // src/mpc.py:265-266
     struct_grad<SmemF<TV>, TV, N>(s, tid);
     for (int i = tid; i < (N + 1) * 13; i += NT) {
@@ -976,11 +1020,13 @@ mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ cta
     }
     const int max_iter = cfgp->max_iter, polish_max = cfgp->polish_max;
     int ok = 0;
-    if (lds<TV>().warm) {   // warm start: the guess's own active set first, no ADMM unless that fails
-      for (int ps = 0; ps < polish_max && ps < WARM_POLISH && !ok; ++ps) ok = ph_polish_step<TV>();
+    const int warm = lds<TV>().warm;
+    if (warm) {   // warm start: the guess's own active set first, no ADMM unless that fails
+      const int tries = warm == 1 ? WARM_POLISH : (warm == 2 ? 1 : 0);
+      for (int ps = 0; ps < polish_max && ps < tries && !ok; ++ps) ok = ph_polish_step<TV>();
     }
     for (int round = 0; !ok; ++round) {
-      ph_admm<TV>(cfgp, round == 0 ? 1 : 0);
+      ph_admm<TV>(cfgp, round == 0 ? 1 : 0, (round == 0 && warm >= 2) ? WARM_K : 0);
       SmemF<TV>& s = lds<TV>();
       const int budget = (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
       for (int ps = 0; ps < budget && !ok; ++ps) ok = ph_polish_step<TV>();
@@ -990,7 +1036,7 @@ mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ cta
       if (tid == 0 && isfinite(ratio) && (ratio > 2.f || ratio < 0.5f)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
       __syncthreads();
     }
-    ph_output<TV, TIO>(ug, Xg, statusg, itersg, resg, b, ok);
+    ph_output<TV, TIO>(ug, Xg, statusg, itersg, resg, in.y_state, b, ok);
 #ifdef MPCQP_STAMPS
     if (tid == 0 && b < 65536) {
       unsigned hw, xcc;

@@ -54,6 +54,8 @@ struct mpcqp_engine {
   int* order_mem = nullptr;   // dispatch order of the fast path: [16 header ints: class counters, queue head | ORDER_BUCKETS x order_cap indices]
   int order_cap = 0;
   int slots = 0;              // workgroups the device holds at once (2 per CU)
+  float* dual_mem = nullptr;  // warm-started engines: multipliers of the previous solve per batch slot [dual_cap][200]
+  int64_t dual_cap = 0;
   bool timed = false;
   char err[512];
 };
@@ -112,6 +114,20 @@ hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* 
     hipLaunchKernelGGL((mpcqp_fast_solve<float, TIO, GAIT>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
                        st, it, res, ob, (int)B);
   return hipGetLastError();
+}
+
+// The per-slot multiplier record of a warm-started engine (grown to the largest batch seen; new slots start at zero = none).
+float* warm_duals(mpcqp_engine* e, int64_t B) {
+  if (!(e->cfg.flags & MPCQP_FLAG_WARM_START)) return nullptr;
+  if (e->dual_cap < B) {
+    float* mem = nullptr;
+    if (hipMalloc(&mem, (size_t)B * 200 * sizeof(float)) != hipSuccess) return e->dual_cap >= B ? e->dual_mem : nullptr;
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(mem, 0, (size_t)B * 200 * sizeof(float));
+    if (e->dual_mem) { (void)hipMemcpy(mem, e->dual_mem, (size_t)e->dual_cap * 200 * sizeof(float), hipMemcpyDeviceToDevice); (void)hipFree(e->dual_mem); }
+    e->dual_mem = mem; e->dual_cap = B;
+  }
+  return e->dual_mem;
 }
 
 bool fast_path_applies(const mpcqp_engine* h) {
@@ -237,6 +253,7 @@ int mpcqp_destroy(mpcqp_handle h) {
   if (h->ctab) (void)hipFree(h->ctab);
   if (h->dcfg) (void)hipFree(h->dcfg);
   if (h->order_mem) (void)hipFree(h->order_mem);
+  if (h->dual_mem) (void)hipFree(h->dual_mem);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   delete h;
@@ -255,16 +272,18 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
   hipError_t he = hipSuccess;
   const bool fast = fast_path_applies(h);
   const bool warm = (h->cfg.flags & MPCQP_FLAG_WARM_START) != 0;   // u_out is read as the initial guess first
+  float* ys = (warm && fast && B > 0) ? warm_duals(h, B) : nullptr;
+  const int shift = (h->cfg.flags & MPCQP_FLAG_WARM_SHIFT) ? 1 : 0;
   he = hipEventRecord(h->ev0, st);
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
   if (B > 0 && fast) {
     if (h->cfg.dtype == MPCQP_DTYPE_F64) {
       const FastIn<double> in = {(const double*)x0, (const double*)r, contact, (const double*)xdes, (const double*)mu,
-                                 nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const double*)u_out : nullptr};
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const double*)u_out : nullptr, ys, shift};
       he = launch_fast<double, false>(h, B, in, u_out, X_out, status, iters, res, st);
     } else {
       const FastIn<float> in = {(const float*)x0, (const float*)r, contact, (const float*)xdes, (const float*)mu,
-                                nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const float*)u_out : nullptr};
+                                nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const float*)u_out : nullptr, ys, shift};
       he = launch_fast<float, false>(h, B, in, u_out, X_out, status, iters, res, st);
     }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
@@ -295,18 +314,20 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
     return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: needs N = 10, MIXED or F32 precision, polish, alpha > 0");
   hipStream_t st = (hipStream_t)stream;
   const bool warm = (h->cfg.flags & MPCQP_FLAG_WARM_START) != 0;
+  float* ys = (warm && B > 0) ? warm_duals(h, B) : nullptr;
+  const int shift = (h->cfg.flags & MPCQP_FLAG_WARM_SHIFT) ? 1 : 0;
   hipError_t he = hipEventRecord(h->ev0, st);
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
   if (B > 0) {
     if (h->cfg.dtype == MPCQP_DTYPE_F64) {
       const FastIn<double> in = {(const double*)x0, nullptr, nullptr, nullptr, (const double*)mu, (const double*)ref,
                                  (const double*)feet0, (const double*)footholds, gait, feet_id,
-                                 warm ? (const double*)u_out : nullptr};
+                                 warm ? (const double*)u_out : nullptr, ys, shift};
       he = launch_fast<double, true>(h, B, in, u_out, X_out, status, iters, res, st);
     } else {
       const FastIn<float> in = {(const float*)x0, nullptr, nullptr, nullptr, (const float*)mu, (const float*)ref,
                                 (const float*)feet0, (const float*)footholds, gait, feet_id,
-                                warm ? (const float*)u_out : nullptr};
+                                warm ? (const float*)u_out : nullptr, ys, shift};
       he = launch_fast<float, true>(h, B, in, u_out, X_out, status, iters, res, st);
     }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);

@@ -20,7 +20,8 @@ def _torch():
 class MPCBatch:
     """One engine handle on one GPU.  All tensors live on ``cuda:<device>``; nothing is copied to the host."""
 
-    def __init__(self, N=10, delta=0.03, device=0, io_dtype="f32", precision="mixed", warm_start=False, **overrides):
+    def __init__(self, N=10, delta=0.03, device=0, io_dtype="f32", precision="mixed", warm_start=False, warm_shift=False,
+                 **overrides):
         """``warm_start=True`` sets MPCQP_FLAG_WARM_START: every solve is seeded with the forces already in the output
         buffer -- the previous solve's solution unless ``u_init`` is passed -- like ``opt.set_initial(U, sol.value(U))``
         in the reference (src/mpc.py:270-271)."""
@@ -30,6 +31,8 @@ class MPCBatch:
         lib = _capi.product_library()
         if warm_start:
             overrides["flags"] = int(overrides.get("flags", _capi.FLAG_POLISH)) | _capi.FLAG_WARM_START
+            if warm_shift:   # the buffer holds the previous control tick's solution: the engine shifts it (and its duals)
+                overrides["flags"] |= _capi.FLAG_WARM_SHIFT
         self.warm_start = bool(warm_start)
         cfg = lib.default_config(N=N, delta=delta, device=device,
                                  dtype={"f32": _capi.DTYPE_F32, "f64": _capi.DTYPE_F64}[io_dtype],

@@ -97,9 +97,11 @@ class MPC:
     def _make_solver(self, device, precision, engine_overrides):
         """The HIP engine.  (tests/ override this hook to drive the same surface with the CPU checker.)"""
         # The reference seeds every solve with the previous solution (`opt.set_initial(U, sol.value(U))`,
-        # src/mpc.py:270-271).  Pass warm_start=True for the same behaviour (MPCQP_FLAG_WARM_START; the guess is moved
-        # up by one stage below).  Off by default: the optimum is the same and, measured, a one-tick-old guess does not
-        # shorten the solve (DESIGN.md, "Warm start").
+        # src/mpc.py:270-271).  Pass warm_start=True for that (MPCQP_FLAG_WARM_START | MPCQP_FLAG_WARM_SHIFT: the engine
+        # keeps the last solution and its multipliers and moves both up by one stage, the horizon step being the control
+        # tick, src/main.py:32 / src/mpc.py:33).  Same optimum either way; off by default (DESIGN.md, "Warm start").
+        if engine_overrides.get("warm_start"):
+            engine_overrides.setdefault("warm_shift", True)
         return MPCBatch(N=self.N, delta=self.delta, device=device, io_dtype="f64", precision=precision, **engine_overrides)
 
     def _solve_one(self, x0, r, contact, xdes):
@@ -108,12 +110,7 @@ class MPC:
                                    "mu": np.array([float(self.mu)])})
         out = self._solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], want_X=True)
         torch.cuda.synchronize(self._solver.device)
-        res = out["u"][0].cpu().numpy(), out["X"][0].cpu().numpy(), int(out["status"][0].item())
-        if getattr(self._solver, "warm_start", False):
-            # next tick's initial guess: this solution moved up by one stage (the horizon step equals the control
-            # tick, src/main.py:32 / src/mpc.py:33); the reference keeps it unshifted -- same optimum either way
-            out["u"][:, :-1] = out["u"][:, 1:].clone()
-        return res
+        return out["u"][0].cpu().numpy(), out["X"][0].cpu().numpy(), int(out["status"][0].item())
 
     # the reference keeps these on the instance and mutates them every tick
     @property

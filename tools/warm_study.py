@@ -1,4 +1,4 @@
-"""Developer tool: how much a warm start saves on a synthetic next-tick batch (cold vs unshifted vs shifted guess)."""
+"""Developer tool: how much a warm start saves on a synthetic next-tick batch."""
 import os, sys, time
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,26 +11,28 @@ from test_gpu_warm_start import next_tick, run
 B = 4096
 b = mpcqp.synth.config3(B)
 cold = mpcqp.MPCBatch(N=10, io_dtype="f64", precision="mixed")
-warm = mpcqp.MPCBatch(N=10, io_dtype="f64", precision="mixed", warm_start=True)
 c0 = run(cold, b)
 nb = next_tick(b, c0["X"])
-dev = cold.upload(nb)
-def timed(sol, u_init=None):
-    for _ in range(3):
-        out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], u_init=u_init)
-    torch.cuda.synchronize()
-    ms = []
-    for _ in range(5):
-        out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], u_init=u_init)
-        torch.cuda.synchronize()
-        ms.append(sol.last_kernel_ms())
-    return np.median(ms), out["iters"].cpu().numpy(), out["status"].cpu().numpy(), out["u"].cpu().numpy().copy()
-ms, it, st, uc = timed(cold)
-print(f"cold      : {ms:.3f} ms  admm {np.mean(it % 1000):6.1f}  polish {np.mean(it // 1000):.2f}  solved {np.mean((st==1)|(st==2)):.4f}")
+c1 = run(cold, nb)
+uc = c1["u"]
+def report(name, sol, out):
+    it = out["iters"]; st = out["status"]
+    ok = (st == 1) | (st == 2)
+    err = np.abs(out["u"] - uc).max(axis=(1, 2)) / np.maximum(np.abs(uc).max(axis=(1, 2)), 1.0)
+    print(f"{name:34s}: {sol.last_kernel_ms():.3f} ms  admm {np.mean(it % 1000):6.1f}  polish {np.mean(it // 1000):.2f}  solved {ok.mean():.4f}  "
+          f"no-ADMM {np.mean(it % 1000 == 0):.3f}  max dev from cold {err[ok].max():.1e}")
+report("cold (tick t+1)", cold, c1)
 shifted = np.ascontiguousarray(np.concatenate([c0["u"][:, 1:], c0["u"][:, -1:]], axis=1))
-for name, g in (("unshifted", c0["u"]), ("shifted", shifted), ("optimum", uc)):
-    gi = torch.as_tensor(np.ascontiguousarray(g)).cuda()
-    ms, it, st, u = timed(warm, gi)
-    err = np.abs(u - uc).max(axis=(1, 2)) / np.maximum(np.abs(uc).max(axis=(1, 2)), 1.0)
-    print(f"{name:10s}: {ms:.3f} ms  admm {np.mean(it % 1000):6.1f}  polish {np.mean(it // 1000):.2f}  solved {np.mean((st==1)|(st==2)):.4f}  "
-          f"no-ADMM {np.mean(it % 1000 == 0):.3f}  max dev from cold {err[(st==1)|(st==2)].max():.1e}")
+# primal-only guesses on a fresh warm engine (no multiplier record yet)
+for name, g in (("primal only, unshifted", c0["u"]), ("primal only, shifted by caller", shifted), ("primal only, the optimum", uc)):
+    w = mpcqp.MPCBatch(N=10, io_dtype="f64", precision="mixed", warm_start=True)
+    o = run(w, nb, u_init=torch.as_tensor(np.ascontiguousarray(g)).cuda())
+    report(name, w, o)
+# the natural flow: the same engine solved tick t, its buffer and multiplier record carry over
+for name, kw in (("(u, y) carried over, unshifted", {}), ("(u, y) carried over, engine shifts", {"warm_shift": True})):
+    w = mpcqp.MPCBatch(N=10, io_dtype="f64", precision="mixed", warm_start=True, **kw)
+    run(w, b)
+    o = run(w, nb)
+    report(name, w, o)
+    o = run(w, nb)
+    report("   ... same QPs again (fixed point)" if not kw else "   ... same QPs again (shifted!)", w, o)
