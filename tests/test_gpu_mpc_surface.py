@@ -77,6 +77,31 @@ def test_single_robot_receding_horizon_surface(oracle_solve):
     assert rel_err(out["u"].cpu().numpy(), ref["u"]).max() <= 1e-4
 
 
+def test_warm_started_controller_matches_cold_one():
+    """MPC(..., warm_start=True) -- the reference's `opt.set_initial(U, sol.value(U))` (src/mpc.py:270-271), with the engine
+    carrying the solution and its multipliers from tick to tick -- must command the same forces as the cold controller on
+    the same receding-horizon run, with fewer ADMM iterations."""
+    runs = {}
+    for warm in (False, True):
+        params, initial, planner, x0 = _setup()
+        robot = KinematicLite3(planner, x0)
+        mpc = MPC(lite3=robot, initial=initial, footstep_planner=planner, params=params, warm_start=warm)
+        logger = Logger({"params": params, "total_sim_steps": 60})
+        F, its = [], []
+        for t in range(60):
+            robot.t = t
+            forces = mpc.solve(t, logger)
+            assert mpc.status in (1, 2)
+            F.append(np.concatenate([forces[l] for l in LEGS]))
+            its.append(int(mpc._solver._out[(1, True)]["iters"][0].item()) % 1000)
+            robot.x = mpc.x_log[:, 1].copy()
+        runs[warm] = (np.array(F), np.array(its))
+    Fc, ic = runs[False]
+    Fw, iw = runs[True]
+    assert np.abs(Fw - Fc).max() <= 1e-4 * max(1.0, np.abs(Fc).max())     # same commands (states stay in lockstep)
+    assert iw[1:].mean() < 0.8 * ic[1:].mean(), (iw.mean(), ic.mean())
+
+
 def test_fleet_one_call_per_tick(oracle_solve):
     fleet_b, states = [], []
     for k, fs in enumerate(((1, 0, 0, 1), (0, 0, 1, 1), (1, 0, 1, 0), (0, 0, 0, 0))):
