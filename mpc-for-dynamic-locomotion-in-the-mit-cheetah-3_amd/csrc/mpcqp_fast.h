@@ -1,9 +1,10 @@
 // mpcqp_fast.h -- fast path for the benchmarked configuration: horizon 10, ADMM + active-set polish, fp32 matrix
 // tiles with fp64 (MIXED) or fp32 (F32) structured residuals.
 //
-// One kernel, one QP per workgroup, but the phases of the solve are separate NOINLINE device functions that talk to
-// each other only through the workgroup's LDS block (a file-scope __shared__ object, so the callees use plain ds_*
-// addressing):
+// One kernel, one QP per workgroup at a time (small batches: blockIdx = QP; batches that oversubscribe the device:
+// resident workgroups pulling QPs dearest-expected-first from a queue, see "dispatch order" below), but the phases of
+// the solve are separate NOINLINE device functions that talk to each other only through the workgroup's LDS block (a
+// file-scope __shared__ object, so the callees use plain ds_* addressing):
 //   ph_setup        operator tuple -> per-variable response vectors, linear term g
 //   ph_admm         M = H + sigma I + rho G'G -> register tiles -> in-register sweep -> K ADMM iterations (fp32),
 //                   with one early OSQP rho check (residuals tracked locally by the iteration) that rebuilds the matrix
