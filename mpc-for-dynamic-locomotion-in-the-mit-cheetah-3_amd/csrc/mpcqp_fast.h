@@ -909,7 +909,7 @@ MPCQP_PHASE void ph_output(TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __re
 // the line through the feet over the com height h is the friction coefficient a static stance would need, so
 // (d / h) / mu > 1 means saturated cones, a large active set and slow ADMM convergence (two-legged "amble" support at
 // mu = 0.3: 95 % of those QPs trigger the rho adaptation; diagonal "trot" support: 1 %).  Order only: results are per QP.
-constexpr int ORDER_BUCKETS = 8;
+constexpr int ORDER_BUCKETS = 16;
 struct OrderBuf { int* cnt; int* list; int cap; int* head; };   // cnt[ORDER_BUCKETS], list[ORDER_BUCKETS][cap], queue head
 
 __device__ __forceinline__ float support_demand(int nst, const float (&fx)[4], const float (&fy)[4], const float (&fz)[4],
@@ -930,9 +930,18 @@ __device__ __forceinline__ float support_demand(int nst, const float (&fx)[4], c
   return 0.f;   // three or four feet (or flight): no friction-limited moment balance
 }
 
-// 16 lanes per QP, one stage (or one planned step) per lane: the loads of a QP go out together, a DPP row reduction
-// takes the maximum, lane 0 files the QP.
-// The class counters are bumped once per workgroup of 64 QPs (a global atomic per QP on eight addresses serialises).
+// Expected cost of a QP in microseconds above the cheapest one: every stance leg-stage is three pivots in each of the
+// ~2.5 sweeps of a solve (2.2 us), and a unit of friction demand (capped at 2) costs 34 us of extra ADMM blocks and polish
+// steps -- least squares on measured per-QP times of the bench workload (tools/timeline.py; correlation 0.48, enough for
+// the order: the makespan model drops from 1.36 to 1.24 ms, a clairvoyant order reaches 1.19 ms).
+__device__ __forceinline__ int cost_class(float nst, float demand_over_mu) {
+  const float us = 2.2f * nst + 34.f * fminf(demand_over_mu, 2.f);
+  return isfinite(us) ? (int)fminf(us * 0.1f, (float)(ORDER_BUCKETS - 1)) : 0;
+}
+
+// 16 lanes per QP, one stage per lane: the loads of a QP go out together, DPP row reductions take the maximum demand and
+// the stance count, lane 0 files the QP.  The class counters are bumped once per workgroup of 64 QPs (a global atomic
+// per QP on a handful of addresses serialises).
 template <typename TIO, bool GAIT>
 __global__ void __launch_bounds__(1024)
 mpcqp_order_kernel(const FastIn<TIO> in, const int B, const OrderBuf ob) {
@@ -941,35 +950,46 @@ mpcqp_order_kernel(const FastIn<TIO> in, const int B, const OrderBuf ob) {
   if (threadIdx.x < ORDER_BUCKETS) lcnt[threadIdx.x] = 0;
   __syncthreads();
   const int b = blockIdx.x * 64 + (threadIdx.x >> 4), k = threadIdx.x & 15;
-  float score = 0.f;
-  if (b < B && k < (GAIT ? 2 : N)) {
+  float score = 0.f, cnt = 0.f;
+  if (b < B && k < N) {
     float fx[4], fy[4], fz[4]; bool st[4]; int nst = 0;
+    int sidx = 0; bool all_stance = false;
+    if (GAIT) {   // stage k of the horizon: which planned step it falls in, and whether that step is in its swing phase
+      const int tis = in.gait[(size_t)b * 4], ss = in.gait[(size_t)b * 4 + 1], ds = in.gait[(size_t)b * 4 + 2];
+      int tau = tis + k;
+      if (tau >= ss + ds) { tau -= ss + ds; sidx = 1; }
+      all_stance = tau >= ss;
+    }
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       if (!GAIT) {
         const TIO* rp = in.r + ((size_t)b * N + k) * 12 + 3 * l;
         fx[l] = (float)rp[0]; fy[l] = (float)rp[1]; fz[l] = (float)rp[2];
         st[l] = in.contact[((size_t)b * N + k) * 4 + l] != 0;
-      } else {   // the horizon spans at most two steps: their swing patterns on the planned footholds around the reference com
-        const TIO* fp = in.footholds + (size_t)b * 24 + k * 12 + 3 * l;
+      } else {   // planned footholds around the reference com (its drift over the horizon is ignored here)
+        const TIO* fp = in.footholds + (size_t)b * 24 + sidx * 12 + 3 * l;
         fx[l] = (float)fp[0] - (float)in.ref[(size_t)b * 10 + 3]; fy[l] = (float)fp[1] - (float)in.ref[(size_t)b * 10 + 4];
         fz[l] = (float)fp[2] - (float)in.ref[(size_t)b * 10 + 5];
-        st[l] = in.feet_id[(size_t)b * 8 + k * 4 + l] != 0;
+        st[l] = all_stance || in.feet_id[(size_t)b * 8 + sidx * 4 + l] != 0;
       }
       nst += st[l] ? 1 : 0;
     }
     score = support_demand(nst, fx, fy, fz, st);
     if (!isfinite(score)) score = 0.f;
+    cnt = (float)nst;
   }
-  score = fmaxf(score, dpp_mov<0xB1>(score));    // max over the row of 16 lanes (all lanes of the wave are active here)
+  score = fmaxf(score, dpp_mov<0xB1>(score));    // max / sum over the row of 16 lanes (all lanes of the wave are active here)
   score = fmaxf(score, dpp_mov<0x4E>(score));
   score = fmaxf(score, dpp_mov<0x141>(score));
   score = fmaxf(score, dpp_mov<0x140>(score));
+  cnt += dpp_mov<0xB1>(cnt);
+  cnt += dpp_mov<0x4E>(cnt);
+  cnt += dpp_mov<0x141>(cnt);
+  cnt += dpp_mov<0x140>(cnt);
   int bucket = 0, pos = 0;
   const bool filer = b < B && k == 0;
   if (filer) {
-    score /= fmaxf(fabsf((float)in.mu[b]), 1e-3f);
-    bucket = isfinite(score) ? (int)fminf(2.f * score, (float)(ORDER_BUCKETS - 1)) : 0;
+    bucket = cost_class(cnt, score / fmaxf(fabsf((float)in.mu[b]), 1e-3f));
     pos = atomicAdd(&lcnt[bucket], 1);
   }
   __syncthreads();

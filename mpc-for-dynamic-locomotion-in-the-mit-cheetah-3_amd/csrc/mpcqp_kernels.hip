@@ -51,7 +51,7 @@ struct mpcqp_engine {
   double* ctab = nullptr;   // [2][N][N] coefficient tables on the device
   DevCfg* dcfg = nullptr;   // device copy of `dev`
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int* order_mem = nullptr;   // dispatch order of the fast path: [16 header ints: class counters, queue head | ORDER_BUCKETS x order_cap indices]
+  int* order_mem = nullptr;   // dispatch order of the fast path: [32 header ints: class counters, queue head | ORDER_BUCKETS x order_cap indices]
   int order_cap = 0;
   int slots = 0;              // workgroups the device holds at once (2 per CU)
   float* dual_mem = nullptr;  // warm-started engines: multipliers of the previous solve per batch slot [dual_cap][200]
@@ -94,14 +94,14 @@ hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* 
     if (e->order_cap < B) {   // grows with the largest batch seen; the old buffer may still be in use by queued work
       int* mem = nullptr;
       const int64_t cap = ((B + 1023) / 1024) * 1024;
-      if (hipMalloc(&mem, (size_t)(16 + ORDER_BUCKETS * cap) * sizeof(int)) == hipSuccess) {
+      if (hipMalloc(&mem, (size_t)(32 + ORDER_BUCKETS * cap) * sizeof(int)) == hipSuccess) {
         if (e->order_mem) { (void)hipDeviceSynchronize(); (void)hipFree(e->order_mem); }
         e->order_mem = mem; e->order_cap = (int)cap;
       }
     }
     if (e->order_cap >= B) {
-      ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 16; ob.cap = e->order_cap;
-      hipError_t he = hipMemsetAsync(ob.cnt, 0, 16 * sizeof(int), s);
+      ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 32; ob.cap = e->order_cap;
+      hipError_t he = hipMemsetAsync(ob.cnt, 0, 32 * sizeof(int), s);
       if (he != hipSuccess) return he;
       hipLaunchKernelGGL((mpcqp_order_kernel<TIO, GAIT>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
       grid = dim3((unsigned)(B < e->slots ? B : e->slots));   // queued form: resident workgroups pull QPs
