@@ -71,7 +71,7 @@ extern "C" {
                                         reference leaves it; the engine uses its stage k + 1 for stage k (last stage repeated) */
 #define MPCQP_FLAG_GENERAL_KERNEL 4u /* product library: use the single-launch general kernel even where the fast path applies */
 #define MPCQP_FLAG_NATURAL_ORDER 8u  /* product library: one workgroup per QP in batch order.  By default a batch that
-                                        oversubscribes the device (>= 4 QPs per CU) is solved by resident workgroups that pull
+                                        oversubscribes the device (more than 2 QPs per CU) is solved by resident workgroups that pull
                                         QPs dearest-expected-first from a queue (a pre-pass ranks the support patterns by
                                         friction demand): same per-QP results, shorter launch */
 

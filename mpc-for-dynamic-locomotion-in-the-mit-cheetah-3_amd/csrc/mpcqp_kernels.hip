@@ -89,8 +89,8 @@ hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* 
                        float* res, hipStream_t s) {
   dim3 grid((unsigned)B);
   OrderBuf ob = {nullptr, nullptr, 0, nullptr};
-  // dispatch order (mpcqp_fast.h): worth a pre-pass only when the batch oversubscribes the workgroup slots
-  if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && e->slots > 0 && B >= 2 * (int64_t)e->slots) {
+  // dispatch order (mpcqp_fast.h): worth a pre-pass as soon as the batch oversubscribes the workgroup slots
+  if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && e->slots > 0 && B > (int64_t)e->slots) {
     if (e->order_cap < B) {   // grows with the largest batch seen; the old buffer may still be in use by queued work
       int* mem = nullptr;
       const int64_t cap = ((B + 1023) / 1024) * 1024;

@@ -263,7 +263,7 @@ def test_queued_form_matches_plain_form_bitwise():
     """Batches that oversubscribe the device run in the queued form (resident workgroups pulling QPs
     dearest-expected-first).  It must be a pure re-ordering: outputs bitwise those of the plain
     one-workgroup-per-QP form (MPCQP_FLAG_NATURAL_ORDER), non-finite QPs included, for both entry points."""
-    B = 1100                                                   # just above the switch-over (4 QPs per CU on 256 CUs)
+    B = 1100                                                   # oversubscribed: 2 workgroup slots per CU on 256 CUs
     b = mpcqp.synth.config3(B)
     b["x0"] = b["x0"].copy()
     b["x0"][[5, 700, 1099], 3] = np.nan                        # non-finite inputs: status -1, zero outputs, the queue moves on
