@@ -228,10 +228,15 @@ mpcqp_solve_kernel(const DevCfg* __restrict__ cfgp, const double* __restrict__ c
     {
       int step = 0;
       for (int kc = 0; kc < CT; ++kc) {
+        int emv[CW / 3];                          // the chunk's enable masks, fetched together (no dependent LDS read per leg-stage)
+#pragma unroll
+        for (int cb = 0; cb < CW / 3; ++cb) emv[cb] = s.em[kc * (CW / 3) + cb];
+#pragma unroll
+        for (int cb = 0; cb < CW / 3; ++cb) emv[cb] = __builtin_amdgcn_readfirstlane(emv[cb]);
 #pragma unroll
         for (int cb = 0; cb < CW / 3; ++cb) {
           const int og = kc * (CW / 3) + cb;      // owner leg-stage of this block of three pivots
-          const int em = s.em[og];                // uniform: swing / eliminated variables are identity rows, skipped
+          const int em = emv[cb];                 // uniform: swing / eliminated variables are identity rows, skipped
           if (em == 0) continue;
 #pragma unroll
           for (int rr = 0; rr < 3; ++rr) {
@@ -249,18 +254,19 @@ mpcqp_solve_kernel(const DevCfg* __restrict__ cfgp, const double* __restrict__ c
             for (int r3 = 0; r3 < 3; ++r3) vr[r3] = vb[rbase + r3] * p;
 #pragma unroll
             for (int c2 = 0; c2 < CWP; ++c2) vc[c2] = vb[cc * CWP + c2];
+            // no divergent region in a pivot (mpcqp_fast.h): the owner's pivot row IS the published row, so the same
+            // update with the multiplier 1 - p turns it into p * row; the pivot column is written with selects
+            const T vrr = (leg == og) ? (T)1 - p : vr[rr];
 #pragma unroll
-            for (int r3 = 0; r3 < 3; ++r3)
+            for (int r3 = 0; r3 < 3; ++r3) {
+              const T m = r3 == rr ? vrr : vr[r3];
 #pragma unroll
-              for (int c2 = 0; c2 < CWP; ++c2) tile[r3][c2] -= vr[r3] * vc[c2];
-            if (leg == og) {
-#pragma unroll
-              for (int c2 = 0; c2 < CWP; ++c2) tile[rr][c2] = vc[c2] * p;
+              for (int c2 = 0; c2 < CWP; ++c2) tile[r3][c2] -= m * vc[c2];
             }
-            if (cc == kc) {
 #pragma unroll
-              for (int r3 = 0; r3 < 3; ++r3) tile[r3][c] = vr[r3];
-              if (leg == og) tile[rr][c] = -p;
+            for (int r3 = 0; r3 < 3; ++r3) {
+              const T v = (r3 == rr && leg == og) ? -p : vr[r3];
+              tile[r3][c] = (cc == kc) ? v : tile[r3][c];
             }
             ++step;
           }
