@@ -283,25 +283,31 @@ mpcqp_solve_kernel(const DevCfg* __restrict__ cfgp, const double* __restrict__ c
       const T lo0 = stance ? (T)s.cf.fmin : (T)0, hi0 = stance ? (T)s.cf.fmax : (T)0;  // src/mpc.py:151-157
       const T hiP = stance ? BIG : (T)0;                 // rows f + mu fz >= 0 (src/mpc.py:159-173): [0, inf)
       const T loM = stance ? -BIG : (T)0;                // rows f - mu fz <= 0: (-inf, 0]
+      // The leg-stage's state is spread over its lanes as in the fast path (mpcqp_fast.h, LegLane): lane q = cc & 3 holds
+      // component min(q, 2) and its constraint rows (0: fx and fx -+ mu fz, 1: fy and fy -+ mu fz, 2,3: fz and its box row);
+      // lanes 4..7 mirror 0..3.  Full copies (u3, z5, y5) exist only at the checkpoints, reloaded from LDS.
+      const int q = cc & 3, comp = q < 2 ? q : 2;
+      const int rowA = q == 0 ? 1 : (q == 1 ? 3 : 0), rowB = q == 0 ? 2 : (q == 1 ? 4 : -1);
+      const bool tang = q < 2;
+      const T mA = tang ? -mu : (T)0, mB = tang ? mu : (T)0, aB = tang ? (T)1 : (T)0, kz = tang ? (T)0 : mu;
+      const T loA = !stance ? (T)0 : (tang ? loM : lo0), hiA = !stance ? (T)0 : (tang ? (T)0 : hi0);
+      const T loB = (T)0, hiB = (stance && tang) ? hiP : (T)0;
+      const T gc = (T)s.gl[row0 + comp];
+      T uc_ = s.au[row0 + comp];
+      T zA = s.az[leg * 5 + rowA], yA = s.ay[leg * 5 + rowA];
+      T zB = rowB >= 0 ? s.az[leg * 5 + rowB] : (T)0, yB = rowB >= 0 ? s.ay[leg * 5 + rowB] : (T)0;
+      T wc = 0;
       T g3[3], u3[3], z5[5], y5[5];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { g3[c] = (T)s.gl[row0 + c]; u3[c] = s.au[row0 + c]; }
-#pragma unroll
-      for (int i = 0; i < 5; ++i) { z5[i] = s.az[leg * 5 + i]; y5[i] = s.ay[leg * 5 + i]; }
       int buf = 0;
-      const T inv_rho = (T)1 / rho;
-      auto write_rhs = [&](int bsel) {
-        T v[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) v[i] = rho * z5[i] - y5[i];
-        if (cc == 0) {
-          T* rb = s.rhs + bsel * VP;
-          rb[rbase + 0] = sigma * u3[0] - g3[0] + v[1] + v[2];
-          rb[rbase + 1] = sigma * u3[1] - g3[1] + v[3] + v[4];
-          rb[rbase + 2] = sigma * u3[2] - g3[2] + v[0] + mu * (-v[1] + v[2] - v[3] + v[4]);
-        }
+      const T inv_rho = (T)1 / rho, om = (T)1 - relax;
+      auto update_w = [&]() {   // G'(rho z - y) of my component (+ the mu-coupled part of the tangential lanes on the fz lanes)
+        const T vA = rho * zA - yA, vB = rho * zB - yB;
+        const T d = vB - vA;
+        const T dx = dpp_mov<0x00>(d), dy = dpp_mov<0x55>(d);
+        wc = kz * (dx + dy) + vA + vB;
       };
-      write_rhs(0);
+      update_w();
+      s.rhs[rbase + comp] = sigma * uc_ - gc + wc;
       __syncthreads();
       bool go_polish = false;
       while (it < max_iter) {
@@ -318,32 +324,42 @@ mpcqp_solve_kernel(const DevCfg* __restrict__ cfgp, const double* __restrict__ c
         T ut[3];
 #pragma unroll
         for (int r3 = 0; r3 < 3; ++r3) ut[r3] = -group8_sum(acc[r3]);
-        const T zt[5] = {ut[2], ut[0] - mu * ut[2], ut[0] + mu * ut[2], ut[1] - mu * ut[2], ut[1] + mu * ut[2]};
-        const T lo[5] = {lo0, loM, (T)0, loM, (T)0}, hi[5] = {hi0, (T)0, hiP, (T)0, hiP};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) u3[c] = relax * ut[c] + ((T)1 - relax) * u3[c];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-          const T zr = relax * zt[i] + ((T)1 - relax) * z5[i];
-          T zn = zr + y5[i] * inv_rho;
-          zn = zn < lo[i] ? lo[i] : (zn > hi[i] ? hi[i] : zn);
-          y5[i] += rho * (zr - zn);
-          z5[i] = zn;
+        const T utz = ut[2], utc = q == 0 ? ut[0] : (q == 1 ? ut[1] : ut[2]);
+        uc_ = relax * utc + om * uc_;
+        {
+          const T gA = mA * utz + utc;
+          const T zr = relax * gA + om * zA;
+          T zn = zr + yA * inv_rho;
+          zn = zn < loA ? loA : (zn > hiA ? hiA : zn);
+          yA += rho * (zr - zn);
+          zA = zn;
         }
+        {
+          const T gB = mB * utz + aB * utc;
+          const T zr = relax * gB + om * zB;
+          T zn = zr + yB * inv_rho;
+          zn = zn < loB ? loB : (zn > hiB ? hiB : zn);
+          yB += rho * (zr - zn);
+          zB = zn;
+        }
+        update_w();
         buf ^= 1;
-        write_rhs(buf);
+        s.rhs[buf * VP + rbase + comp] = sigma * uc_ - gc + wc;
         ++it;
         __syncthreads();
         if (it % check_every == 0 || it == max_iter) {
           STAMP(4);
           // park the ADMM state in LDS (frees its registers for the checkpoint / polish) and publish u, y
-          if (cc == 0) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { s.au[row0 + c] = u3[c]; s.uv[row0 + c] = (TV)u3[c]; s.pu[row0 + c] = (TV)u3[c]; }
-#pragma unroll
-            for (int i = 0; i < 5; ++i) { s.az[leg * 5 + i] = z5[i]; s.ay[leg * 5 + i] = y5[i]; s.py[leg * 5 + i] = (TV)y5[i]; }
+          if (cc < 3) {
+            s.au[row0 + comp] = uc_; s.uv[row0 + comp] = (TV)uc_; s.pu[row0 + comp] = (TV)uc_;
+            s.az[leg * 5 + rowA] = zA; s.ay[leg * 5 + rowA] = yA; s.py[leg * 5 + rowA] = (TV)yA;
+            if (rowB >= 0) { s.az[leg * 5 + rowB] = zB; s.ay[leg * 5 + rowB] = yB; s.py[leg * 5 + rowB] = (TV)yB; }
           }
           __syncthreads();
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { g3[c] = (T)s.gl[row0 + c]; u3[c] = s.au[row0 + c]; }
+#pragma unroll
+          for (int i = 0; i < 5; ++i) { z5[i] = s.az[leg * 5 + i]; y5[i] = s.ay[leg * 5 + i]; }
           // residuals of the QP at (u, z, y): |Gu - z|_inf, |grad f(u) + G'y|_inf  (OSQP termination test)
           struct_grad<Smem<T, TV, N>, TV, N>(s, tid);
           float q[4] = {0.f, 0.f, 0.f, 0.f};
