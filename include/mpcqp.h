@@ -97,7 +97,7 @@ typedef struct MpcQpConfig {
   double relax;         /* over-relaxation in (0,2) */
   int32_t max_iter;     /* ADMM iteration cap K */
   int32_t check_every;  /* ADMM block length between polish attempts (iterations); default 100, tuned for N = 10 --
-                           use 10 N (and max_iter 40 N) for other horizons, as the Python host layer does */
+                           scale both with N / 10 for other horizons (200 / 800 at N = 20), as the Python host layer does */
   double eps_abs, eps_rel;
   int32_t polish_max;   /* active-set refinement steps per polish attempt */
   int32_t device;       /* HIP device ordinal (product library) */

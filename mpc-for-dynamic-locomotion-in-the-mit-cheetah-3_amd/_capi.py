@@ -90,10 +90,10 @@ class Library:
         # the ADMM block length is tuned per horizon: 100 iterations at N = 10 (the C default), 200 at N = 20 (measured:
         # +20 % throughput and 100 % instead of 98.8 % solved, tools/n20_knobs.py); explicit overrides win
         n = int(overrides.get("N", cfg.N))
-        if n != 10 and "check_every" not in overrides:
-            cfg.check_every = 10 * n
+        if n != 10 and "check_every" not in overrides:   # scale the library's own N = 10 defaults
+            cfg.check_every = max(1, cfg.check_every * n // 10)
             if "max_iter" not in overrides:
-                cfg.max_iter = 40 * n
+                cfg.max_iter = max(1, cfg.max_iter * n // 10)
         for k, v in overrides.items():
             if k in ("w", "Ibody_inv"):
                 arr = getattr(cfg, k)

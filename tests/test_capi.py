@@ -43,6 +43,22 @@ def test_config_struct_layout_and_defaults(oracle_lib):
         assert cfg.disc == mpcqp.DISC_EULER
 
 
+def test_host_layer_scales_the_admm_block_with_the_horizon(oracle_lib):
+    """The C default (100 iterations per block, cap 400) is tuned for N = 10; the Python host layer uses 10 N / 40 N for
+    other horizons unless the caller says otherwise (include/mpcqp.h, `check_every`)."""
+    for lib in (oracle_lib, mpcqp.product_library()):
+        c10, c20 = lib.default_config(), lib.default_config(N=20)
+        assert (c20.check_every, c20.max_iter) == (2 * c10.check_every, 2 * c10.max_iter)
+        c = lib.default_config(N=20, check_every=50)
+        assert (c.check_every, c.max_iter) == (50, c10.max_iter)
+        assert lib.default_config(N=20, max_iter=1000).max_iter == 1000
+    p10 = mpcqp.product_library().default_config()
+    assert (p10.check_every, p10.max_iter) == (100, 400)
+    flags = mpcqp.product_library().default_config(
+        flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_WARM_START | mpcqp.FLAG_WARM_SHIFT | mpcqp.FLAG_NATURAL_ORDER).flags
+    assert flags == 1 | 2 | 16 | 8
+
+
 def test_product_never_falls_back_to_cpu():
     """Without a gfx950 device the product library refuses to create an engine (MPCQP_ENODEV), it does not emulate."""
     if _have_gpu():
