@@ -103,11 +103,12 @@ def make_xdes(roll0, pitch0, yaw_start, com_start, v_ref, omega_ref, g, N, delta
 # Sparse multiple-shooting form, literal to src/mpc.py:58-173 (duplicates and trivial rows included).
 # Variable order: z = [X[:,0], ..., X[:,N], U[:,0], ..., U[:,N-1]]  (column-major like CasADi's vec()).
 # ----------------------------------------------------------------------------------------------------
-def sparse_qp(x0, r, contact, xdes, mu, cfg: QPConfig):
+def sparse_qp(x0, r, contact, xdes, mu, cfg: QPConfig, labels=False):
     """Returns P, q, c0, Ac, lo, hi with objective 1/2 z'Pz + q'z + c0 and lo <= Ac z <= hi.
 
     x0[13]; r[N,4,3]; contact[N,4] in {0,1} (1 = stance, swing = 1-contact, src/mpc.py:248-254);
-    xdes[N+1,13]; mu scalar.
+    xdes[N+1,13]; mu scalar.  With ``labels=True`` a seventh value names the row class of every constraint row
+    ("x0", "dyn_<state row>", "swing", "gpin", "fz_lo", "fz_hi", "fric_y", "fric_x") for row-class-wise checks.
     """
     N = cfg.N
     nX = NX * (N + 1)
@@ -128,14 +129,14 @@ def sparse_qp(x0, r, contact, xdes, mu, cfg: QPConfig):
     for k in range(N):
         P[iu(k), iu(k)] = 2.0 * cfg.alpha * np.eye(NU)
 
-    rows, lo, hi = [], [], []
+    rows, lo, hi, lab = [], [], [], []
 
-    def add(row, l, h):
-        rows.append(row); lo.append(l); hi.append(h)
+    def add(row, l, h, name):
+        rows.append(row); lo.append(l); hi.append(h); lab.append(name)
 
     for i in range(NX):                                    # src/mpc.py:113
         row = np.zeros(nz); row[i] = 1.0
-        add(row, x0[i], x0[i])
+        add(row, x0[i], x0[i], "x0")
     for k in range(N):                                     # src/mpc.py:116-117
         Ad, Bd = discretise(A, build_B(yaw, r[k], cfg), cfg.delta, cfg.disc)
         for i in range(NX):
@@ -143,36 +144,37 @@ def sparse_qp(x0, r, contact, xdes, mu, cfg: QPConfig):
             row[ix(k + 1)][i] = 1.0
             row[ix(k)] -= Ad[i]
             row[iu(k)] -= Bd[i]
-            add(row, 0.0, 0.0)
+            add(row, 0.0, 0.0, "dyn_%d" % i)
     swing = 1.0 - np.asarray(contact, float)
     for k in range(N):                                     # src/mpc.py:139-144
         for j in range(4):
             for a in range(3):
                 row = np.zeros(nz); row[iu(k)][3 * j + a] = swing[k, j]
-                add(row, 0.0, 0.0)
+                add(row, 0.0, 0.0, "swing")
     g = xdes[0, 12]
     INF = 1e20
     for k in range(N):
         row = np.zeros(nz); row[ix(k)][12] = 1.0           # src/mpc.py:149
-        add(row, g, g)
+        add(row, g, g, "gpin")
         for j in range(4):                                 # src/mpc.py:151-157
             cond = 1.0 - swing[k, j]
             row = np.zeros(nz); row[iu(k)][3 * j + 2] = cond
-            add(row, cond * cfg.f_min, INF)
-            add(row.copy(), -INF, cond * cfg.f_max)
+            add(row, cond * cfg.f_min, INF, "fz_lo")
+            add(row.copy(), -INF, cond * cfg.f_max, "fz_hi")
         for j in range(4):                                 # src/mpc.py:159-165 (y), written twice
             for _dup in range(2):
                 row = np.zeros(nz); row[iu(k)][3 * j + 1] = 1.0; row[iu(k)][3 * j + 2] = mu
-                add(row, 0.0, INF)                         # -mu fz <= fy
+                add(row, 0.0, INF, "fric_y")               # -mu fz <= fy
                 row = np.zeros(nz); row[iu(k)][3 * j + 1] = 1.0; row[iu(k)][3 * j + 2] = -mu
-                add(row, -INF, 0.0)                        # fy <= mu fz
+                add(row, -INF, 0.0, "fric_y")              # fy <= mu fz
         for j in range(4):                                 # src/mpc.py:167-173 (x), written twice
             for _dup in range(2):
                 row = np.zeros(nz); row[iu(k)][3 * j + 0] = 1.0; row[iu(k)][3 * j + 2] = mu
-                add(row, 0.0, INF)
+                add(row, 0.0, INF, "fric_x")
                 row = np.zeros(nz); row[iu(k)][3 * j + 0] = 1.0; row[iu(k)][3 * j + 2] = -mu
-                add(row, -INF, 0.0)
-    return P, q, c0, np.array(rows), np.array(lo), np.array(hi)
+                add(row, -INF, 0.0, "fric_x")
+    out = (P, q, c0, np.array(rows), np.array(lo), np.array(hi))
+    return out + (np.array(lab),) if labels else out
 
 
 # ----------------------------------------------------------------------------------------------------

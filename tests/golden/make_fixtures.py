@@ -136,7 +136,9 @@ def planner_goldens(log):
     pl = FootstepPlanner(initial_from_log(log), params, show=False)
     tg = FootTrajectoryGenerator(pl, params)
     des = np.zeros((1000, 4, 3))
+    phase = np.zeros((1000, 4), dtype=np.uint8)     # contact[0] of the QP solved at tick t (src/mpc.py:249-252, i = 0)
     for t in range(1000):
+        phase[t] = pl.get_phase_at_time(t)          # queried by MPC.solve before the swing controller runs (src/main.py:155-162)
         si = pl.get_step_index_at_time(t)
         gait = list(pl.plan[si]["feet_id"])
         for j, l in enumerate(LEGS):
@@ -148,6 +150,7 @@ def planner_goldens(log):
                     p[2] = 0
                 des[t, j] = p
     out["replay_feet_des"] = des
+    out["replay_phase"] = phase
     out["replay_feet_des_maxerr_vs_log"] = np.float64(np.abs(des - log["feet_des"]).max())
     return out
 

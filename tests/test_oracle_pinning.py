@@ -188,3 +188,170 @@ def test_torque_map_matches_reference_expression(oracle_lib):
     for b in range(B):
         for l in range(4):
             assert np.allclose(tau[b, l], J[b, l].T @ -u[b, 0, 3 * l:3 * l + 3], atol=1e-13)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Output-side pins: every number the reference's committed log holds about its own solver OUTPUTS is checked against
+# the restated QP.  The log keeps (src/logger.py:22-57, src/main.py:216-218, src/mpc.py:297-301): the stage-0 forces
+# of all 1000 solves, and at t = 0 / 80 the predicted states (12 x 61) and the predicted f_z (4 x 60).  f_x / f_y of
+# the predictions were not logged, so rows that involve them (omega / v_xy dynamics, friction of stages >= 1) have no
+# reference-held witness; neither has optimality (OSQP stopped at its default 1e-3 tolerances).
+# ------------------------------------------------------------------------------------------------------------------
+OSQP_EPS = 1e-3          # OSQP default eps_abs = eps_rel (src/mpc.py:51-55 sets only max_iter and verbose)
+
+
+def test_logged_stage0_forces_match_contact_mask_all_ticks(golden):
+    """(a) 1000 ticks: a logged leg force is ~0 exactly when the replayed planner says the leg swings at stage 0
+    (swing_param = 1 - phase, src/mpc.py:139-144,249-252; phase recorded from the reference planner itself)."""
+    L, G = golden["ref_log"], golden["planner_golden"]
+    F = L["forces"].reshape(1000, 4, 3)
+    stance = G["replay_phase"].astype(bool)
+    assert stance.shape == (1000, 4) and (~stance).sum() == 380
+    slack = OSQP_EPS * (1.0 + np.abs(F).max())                       # eps_abs + eps_rel |z|_inf  (~0.1 N)
+    mag = np.abs(F).max(axis=2)
+    assert mag[~stance].max() <= slack                                # swing legs carry no force
+    assert mag[stance].min() >= 3.0 - slack                           # stance legs carry at least f_min
+    assert np.array_equal(mag > 1.0, stance)                          # the two populations are separated by > 2.8 N
+    # our own planner port reproduces the same mask (it feeds contact[] of every product-path test)
+    from mpcqp.footstep_planner import FootstepPlanner
+    from test_planner_glue import _initial, _params
+    pl = FootstepPlanner(_initial(L), _params(L), show=False)
+    assert np.array_equal(np.array([pl.get_phase_at_time(t) for t in range(1000)], dtype=bool), stance)
+
+
+def test_logged_stage0_forces_obey_bounds_and_friction(golden):
+    """(b) logged stance forces obey 3 <= f_z <= 100 (src/mpc.py:45-46,151-157) and |f_xy| <= mu f_z
+    (src/mpc.py:159-173, mu = 1) within OSQP's termination slack."""
+    L, G = golden["ref_log"], golden["planner_golden"]
+    F = L["forces"].reshape(1000, 4, 3)
+    st = G["replay_phase"].astype(bool)
+    mu = float(L["param_mu"])
+    slack = OSQP_EPS * (1.0 + np.abs(F).max())
+    fz = F[st][:, 2]
+    assert fz.min() >= 3.0 - slack and fz.max() <= 100.0 + slack
+    assert (np.abs(F[st][:, :2]).max(axis=1) - mu * fz).max() <= slack
+    # the bounds do bind in the log (so the test would notice a wrong f_min / f_max): some legs sit at the lower bound
+    assert (np.abs(fz - 3.0) <= slack).sum() >= 10 and fz.max() > 90.0
+    # and the restated constants are the only ones compatible: f_min = 4 or mu = 0.5 would be violated by the log
+    assert fz.min() < 4.0 - slack
+    assert (np.abs(F[st][:, :2]).max(axis=1) - 0.5 * fz).max() > slack
+
+
+def _logged_prediction_vs_sparse_rows(golden, i, t, mutate=None):
+    """Residual of the logged prediction i (tick t) on every row of the literal sparse QP (src/mpc.py:113-173) whose
+    variables were all logged; returns {row class: max violation}, the OSQP termination bound, and J_log."""
+    L, q = golden["ref_log"], golden["qp_inputs"]
+    N = 60
+    cfg = S.QPConfig(N=N, delta=0.01, alpha=0.0)
+    j = int(np.where(q["ticks"] == t)[0][0])
+    x0, r, c, xd, mu = _qp(golden, N, j)
+    P, qv, c0, A, lo, hi, lab = S.sparse_qp(x0, r, c, xd, mu, cfg, labels=True)
+    if mutate:
+        A, lo, hi = mutate(A.copy(), lo.copy(), hi.copy(), lab, c)
+    nX = 13 * (N + 1)
+    z = np.full(nX + 12 * N, np.nan)
+    z[:nX] = np.vstack([L[f"pred{i}_state"], np.full((1, N + 1), -9.81)]).T.reshape(-1)
+    z[nX + 2::3] = L[f"pred{i}_fz"].T.reshape(-1)                     # f_z of leg l, stage k at 12 k + 3 l + 2
+    known = ~np.isnan(z)
+    rows_ok = ~np.any((A != 0) & ~known[None, :], axis=1)
+    Az = A @ np.where(known, z, 0.0)
+    viol = np.maximum(np.maximum(lo - Az, Az - hi), 0.0)
+    out = {name: float(viol[(lab == name) & rows_ok].max()) for name in np.unique(lab) if ((lab == name) & rows_ok).any()}
+    bound = OSQP_EPS + OSQP_EPS * max(np.abs(Az[rows_ok]).max(), np.abs(z[known]).max())
+    return out, bound, int(rows_ok.sum())
+
+
+@pytest.mark.parametrize("i,t", [(0, 0), (1, 80)])
+def test_logged_predictions_meet_osqp_primal_bound_on_sparse_rows(golden, i, t):
+    """(c) the (X, f_z) OSQP logged at t = 0 / 80 satisfies the restated constraint matrix row class by row class to
+    OSQP's primal termination bound eps_abs + eps_rel max(|Az|, |z|): pins signs / scales of A, l, u in the blocks
+    initial state, Theta / p / v_z / g dynamics, gravity pin, swing rows, f_z box."""
+    res, bound, nrows = _logged_prediction_vs_sparse_rows(golden, i, t)
+    assert nrows >= 1500
+    want = {"x0", "dyn_0", "dyn_1", "dyn_2", "dyn_3", "dyn_4", "dyn_5", "dyn_11", "dyn_12", "gpin", "swing", "fz_lo", "fz_hi"}
+    assert want <= set(res)
+    assert not ({"dyn_6", "dyn_7", "dyn_8", "dyn_9", "dyn_10", "fric_x", "fric_y"} & set(res))   # need f_x / f_y: not logged
+    assert 0.05 < bound < 0.1
+    for name in want:
+        assert res[name] <= bound, (name, res[name], bound)
+    # observed levels (regression pins, far below the bound): Euler rows hold to 4e-3, box rows exactly
+    assert max(res[k] for k in ("dyn_0", "dyn_1", "dyn_2", "dyn_3", "dyn_4", "dyn_5", "dyn_11", "x0")) <= 4e-3
+    assert res["fz_lo"] == 0.0 and res["fz_hi"] == 0.0 and res["gpin"] == 0.0 and res["swing"] <= 2.5e-2
+
+
+def _mut_gravity_sign(A, lo, hi, lab, c):          # A[11,12] = -1 instead of +1 (src/mpc.py:94)
+    rows = np.where(lab == "dyn_11")[0]
+    for k, rw in enumerate(rows):
+        A[rw, 13 * k + 12] *= -1
+    return A, lo, hi
+
+
+def _mut_force_sign(A, lo, hi, lab, c):            # forces enter v_z with the wrong sign (src/mpc.py:105-107,117)
+    rows = np.where(lab == "dyn_11")[0]
+    A[np.ix_(rows, np.arange(13 * 61, A.shape[1]))] *= -1
+    return A, lo, hi
+
+
+def _mut_mass(A, lo, hi, lab, c):                  # m = 8.885 / 2
+    rows = np.where(lab == "dyn_11")[0]
+    A[np.ix_(rows, np.arange(13 * 61, A.shape[1]))] *= 2
+    return A, lo, hi
+
+
+def _mut_velocity_sign(A, lo, hi, lab, c):         # p+ = p - delta v (src/mpc.py:92,117)
+    for a in range(3):
+        rows = np.where(lab == "dyn_%d" % (3 + a))[0]
+        for k, rw in enumerate(rows):
+            A[rw, 13 * k + 9 + a] *= -1
+    return A, lo, hi
+
+
+def _mut_swing_inverted(A, lo, hi, lab, c):        # swing_param = phase instead of 1 - phase (src/mpc.py:251)
+    rows = np.where(lab == "swing")[0]
+    cols = 13 * 61 + np.arange(720)
+    A[rows, cols] = 1.0 - A[rows, cols]
+    return A, lo, hi
+
+
+def _mut_box_swapped(A, lo, hi, lab, c):           # f_min and f_max exchanged (src/mpc.py:45-46)
+    lo[lab == "fz_lo"] *= 100.0 / 3.0
+    hi[lab == "fz_hi"] *= 3.0 / 100.0
+    return A, lo, hi
+
+
+def _mut_x0_sign(A, lo, hi, lab, c):               # X[:,0] == -x0 (src/mpc.py:113)
+    rows = np.where(lab == "x0")[0]
+    lo[rows] *= -1; hi[rows] *= -1
+    return A, lo, hi
+
+
+@pytest.mark.parametrize("mutate,cls,beyond_bound", [
+    (_mut_gravity_sign, "dyn_11", True), (_mut_force_sign, "dyn_11", True), (_mut_mass, "dyn_11", True),
+    (_mut_swing_inverted, "swing", True), (_mut_box_swapped, "fz_lo", True), (_mut_x0_sign, "x0", True),
+    (_mut_velocity_sign, "dyn_3", False)])
+def test_sign_or_scale_error_in_a_block_is_caught_by_the_log(golden, mutate, cls, beyond_bound):
+    """Demonstration that (c) discriminates: one flipped sign / wrong scale in a block breaks the OSQP bound on that row
+    class (or, for the position rows where 2 delta |v| is below OSQP's slack, at least triples the residual)."""
+    base, bound, _ = _logged_prediction_vs_sparse_rows(golden, 0, 0)
+    bad, _, _ = _logged_prediction_vs_sparse_rows(golden, 0, 0, mutate)
+    if beyond_bound:
+        assert bad[cls] > bound and bad[cls] > 10 * base[cls], (cls, base[cls], bad[cls], bound)
+    else:
+        assert bad[cls] > 3 * base[cls], (cls, base[cls], bad[cls])
+
+
+def test_logged_prediction_objective_gap(golden):
+    """(d) J_log - J_oracle >= 0 at both logged ticks (reference cost, alpha = 0, N = 60): the oracle's optimum is never
+    worse than what OSQP returned.  (The gap is large -- J_log / J_oracle = 2.8 at t = 0, 2.2 at t = 80 -- because
+    OSQP's default dual tolerance eps_rel |q|_inf ~ 150 leaves the force distribution essentially undetermined.)"""
+    L, q = golden["ref_log"], golden["qp_inputs"]
+    cfg = S.QPConfig(N=60, delta=0.01, alpha=0.0)
+    for i, t in ((0, 0), (1, 80)):
+        j = int(np.where(q["ticks"] == t)[0][0])
+        xd = q["N60_xdes"][j]
+        Xlog = np.vstack([L[f"pred{i}_state"], np.full((1, 61), -9.81)]).T
+        Jlog = S.objective(Xlog, np.zeros(1), xd, cfg)
+        Jor = float(golden["qp_optima"]["N60_a0_J"][j])
+        gap = Jlog - Jor
+        assert gap >= -1e-9 * abs(Jlog)
+        assert Jor > 0.2 * Jlog, (Jlog, Jor)                   # same order of magnitude: same cost function, same weights
