@@ -17,9 +17,14 @@ from .foot_trajectory_generator import FootTrajectoryGenerator
 from .footstep_planner import LEGS, FootstepPlanner
 from .logger import Logger
 
-DEFAULT_PARAMS = {           # src/main.py:31-46 with the benchmark horizon / step
-    "g": -9.81, "h": 0.285, "step_height": 0.08, "ss_duration": 10, "ds_duration": 5, "world_time_step": 0.03,
-    "total_steps": 20, "first_swing": np.array([1, 0, 0, 1]), "µ": 1, "N": 10, "dof": 18,
+# src/main.py:31-46 with the benchmark horizon / step (BASELINE config 1: N = 10, dt = 0.03 s).  The reference states its
+# step durations in TICKS of its 0.01 s world step (ss 10 = 0.10 s, ds 5 = 0.05 s, src/main.py:35-36,41); config 1 keeps
+# those durations IN SECONDS, i.e. 4 and 2 ticks of 0.03 s (0.12 s / 0.06 s).  Keeping the tick counts instead would
+# mean 0.3 s of two-leg support per step with a 0.3 s horizon -- a different (and, in this formulation, diverging)
+# gait: DESIGN.md section 10.  total_steps is raised so that the 300-tick run walks throughout (50 x 6 ticks).
+DEFAULT_PARAMS = {
+    "g": -9.81, "h": 0.285, "step_height": 0.08, "ss_duration": 4, "ds_duration": 2, "world_time_step": 0.03,
+    "total_steps": 50, "first_swing": np.array([1, 0, 0, 1]), "µ": 1, "N": 10, "dof": 18,
     "v_com_ref": np.array([0.18, 0.0, 0.0]), "theta_dot": 0.0, "log_samples": 300,
 }
 

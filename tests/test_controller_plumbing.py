@@ -37,12 +37,19 @@ def test_leg_jacobian_matches_finite_differences():
 def test_config1_closed_loop_plumbing(oracle_lib):
     ctl = Lite3Controller(OracleMPC)
     T = 300
-    contact = []
+    contact, xs = [], []
     for t in range(T):
         contact.append(ctl.footstep_planner.get_phase_at_time(t))     # before the tick: the swing query below mutates feet_id
         tau = ctl.customPreStep()
         assert set(tau) == set(mpcqp.footstep_planner.LEGS) and all(np.all(np.isfinite(v)) for v in tau.values())
         assert ctl.mpc.status in (1, 2)
+        xs.append(ctl.lite3.x.copy())
+    xs = np.array(xs)
+    # tracking over ALL 300 ticks (the reference's acceptance is visual, src/plot.py; these are the same quantities):
+    # height within 2 cm, mean forward speed within 0.05 m/s of v_ref = 0.18 while the plan walks, pitch / roll small
+    assert np.abs(xs[:, 5] - 0.285).max() < 0.02
+    assert abs(xs[:294, 9].mean() - 0.18) < 0.05
+    assert np.abs(xs[:, 1]).max() < 0.1 and np.abs(xs[:, 0]).max() < 0.1 and np.abs(xs[:, 4]).max() < 0.05
     log = ctl.logger.log
     assert len(log["time array"]) == T and len(log["TRACKING PERFORMANCE"]["actual"]) == T
     assert all(len(log["FORCES"][l]["z"]) == T for l in log["FORCES"])
@@ -52,15 +59,11 @@ def test_config1_closed_loop_plumbing(oracle_lib):
     # trot: diagonal pairs alternate; a swing leg carries exactly zero force, stance legs respect 3 <= fz <= 100
     contact = np.array(contact).T
     assert np.all(fz[contact == 0] == 0) and np.all(fz[contact == 1] >= 3 - 1e-6) and np.all(fz <= 100 + 1e-6)
-    # while all four feet are down (first step of the plan) the body is carried and tracks the reference height.
-    # (Later the kinematic stand-in drifts: with N = 10 the lever arms of stages >= 1 are taken relative to the REFERENCE
-    # com, as in src/mpc.py:228-239, which is not stabilising once the body has run ahead -- a property of this toy
-    # world and horizon, not of the solver; every tick is still solved to optimality, see the status assertion above.)
-    assert abs(fz[:, :15].sum(axis=0).mean() - 8.885 * 9.81) < 0.15 * 8.885 * 9.81
-    assert np.all(np.isfinite(ctl.lite3.x))
+    # the body is carried: mean total vertical force = weight
+    assert abs(fz.sum(axis=0).mean() - 8.885 * 9.81) < 0.05 * 8.885 * 9.81
     # reference roll-forward of the targets (src/mpc.py:261-262)
-    # ... which stops on the last plan step (src/mpc.py:181-183): 19 moving steps of 15 ticks
-    assert abs(ctl.mpc.com_pos_start[0] - 19 * 15 * 0.03 * 0.18) < 1e-9
+    # ... which stops on the last plan step (src/mpc.py:181-183): 49 moving steps of 6 ticks
+    assert abs(ctl.mpc.com_pos_start[0] - 49 * 6 * 0.03 * 0.18) < 1e-9
     # log dump / reload without pickle
     import os, tempfile
     with tempfile.TemporaryDirectory() as d:
