@@ -70,6 +70,8 @@ extern "C" {
 #define MPCQP_FLAG_WARM_SHIFT 16u    /* with WARM_START: the guess is the PREVIOUS control tick's solution, left in u_out unshifted as the
                                         reference leaves it; the engine uses its stage k + 1 for stage k (last stage repeated) */
 #define MPCQP_FLAG_GENERAL_KERNEL 4u /* product library: use the single-launch general kernel even where the fast path applies */
+#define MPCQP_FLAG_TILE_KERNEL 32u    /* product library: use the round-1 120 x 120 register-tile kernel (mpcqp_fast.h) even where the
+                                        wrench-space engine (mpcqp_wrench.h) applies; for A/B measurements */
 #define MPCQP_FLAG_NATURAL_ORDER 8u  /* product library: one workgroup per QP in batch order.  By default a batch that
                                         oversubscribes the device (more than 2 QPs per CU) is solved by resident workgroups that pull
                                         QPs dearest-expected-first from a queue (a pre-pass ranks the support patterns by
@@ -110,8 +112,22 @@ uint32_t mpcqp_version(void);
 /* Fill *cfg with the reference's constants (N=10, delta=0.03 of the benchmark configs) and engine defaults. */
 int mpcqp_default_config(MpcQpConfig* cfg);
 
+/*
+ * Handles and devices.  A handle belongs to the device cfg->device; every entry point switches to that device for the
+ * duration of the call and restores the caller's current device before it returns.  A handle serves ONE stream at a time:
+ * its dispatch queue, timing events and warm-start record are per handle, so concurrent solves on two streams need two
+ * handles (any number of handles may share a device).  Not thread-safe per handle.
+ */
 int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out);
 int mpcqp_destroy(mpcqp_handle h);
+
+/*
+ * Pre-size the batch-dependent workspace (dispatch-order buffer; multiplier record of warm-started engines) for batches
+ * of up to B QPs.  Synchronous.  Optional: a solve at a larger B than any reserved or seen before grows the workspace
+ * itself, which costs one device-wide synchronisation + allocation inside that call; after mpcqp_reserve(h, B) no solve
+ * of at most B QPs allocates or synchronises.
+ */
+int mpcqp_reserve(mpcqp_handle h, int64_t B);
 
 /*
  * Solve B independent QPs.  Layouts (row-major, batch outermost; T = cfg.dtype):
@@ -127,7 +143,7 @@ int mpcqp_destroy(mpcqp_handle h);
  *   iters   i32[B]           ADMM iterations used (+ 1000 * polish refinement steps)
  *   res     f32[B,2]         final primal / dual residual (inf-norm); may be NULL
  * `stream` is a hipStream_t (product) or ignored (oracle).  Asynchronous on the stream; the caller owns all
- * buffers; no allocation happens after the first call at a given B.
+ * buffers; no allocation happens after mpcqp_reserve(h, B) / the first call at a given B.
  */
 int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, const uint8_t* contact,
                       const void* xdes, const void* mu, void* u_out, void* X_out, int32_t* status,

@@ -21,11 +21,11 @@ STATUS_UNSOLVED, STATUS_SOLVED_POLISHED, STATUS_SOLVED_ADMM, STATUS_MAX_ITER, ST
 DISC_EULER, DISC_ZOH = 0, 1
 DTYPE_F32, DTYPE_F64 = 0, 1
 PREC_F32, PREC_MIXED, PREC_F64 = 0, 1, 2
-FLAG_POLISH, FLAG_WARM_START, FLAG_GENERAL_KERNEL, FLAG_NATURAL_ORDER, FLAG_WARM_SHIFT = 1, 2, 4, 8, 16
+FLAG_POLISH, FLAG_WARM_START, FLAG_GENERAL_KERNEL, FLAG_NATURAL_ORDER, FLAG_WARM_SHIFT, FLAG_TILE_KERNEL = 1, 2, 4, 8, 16, 32
 
 EXPORTED_SYMBOLS = (
     "mpcqp_version", "mpcqp_default_config", "mpcqp_create", "mpcqp_destroy", "mpcqp_solve_batch",
-    "mpcqp_solve_batch_gait", "mpcqp_torque_map", "mpcqp_last_kernel_ms", "mpcqp_last_error",
+    "mpcqp_solve_batch_gait", "mpcqp_torque_map", "mpcqp_last_kernel_ms", "mpcqp_last_error", "mpcqp_reserve",
 )
 
 
@@ -67,6 +67,8 @@ class Library:
         L.mpcqp_create.argtypes = [ctypes.POINTER(MpcQpConfig), ctypes.POINTER(c_void_p)]
         L.mpcqp_create.restype = c_int32
         L.mpcqp_destroy.argtypes = [c_void_p]
+        L.mpcqp_reserve.argtypes = [c_void_p, c_int64]
+        L.mpcqp_reserve.restype = ctypes.c_int
         L.mpcqp_destroy.restype = c_int32
         L.mpcqp_solve_batch.argtypes = [c_void_p, c_int64] + [c_void_p] * 11
         L.mpcqp_solve_batch.restype = c_int32
@@ -130,6 +132,12 @@ class Engine:
 
     def last_error(self) -> str:
         return (self.library.lib.mpcqp_last_error(self._h) or b"").decode()
+
+    def reserve(self, B):
+        """Pre-size the batch-dependent workspace so that no later solve of at most B QPs allocates or synchronises."""
+        rc = self.library.lib.mpcqp_reserve(self._h, int(B))
+        if rc != 0:
+            raise MpcQpError(f"mpcqp_reserve failed with code {rc}: {self.last_error()}")
 
     def solve_batch_ptr(self, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, stream=0):
         """Raw call: every argument is an integer address (device memory for the product library)."""

@@ -17,6 +17,7 @@
 
 #include "mpcqp_general.h"
 #include "mpcqp_fast.h"
+#include "mpcqp_wrench.h"
 
 #include <cstdio>
 #include <cstring>
@@ -54,6 +55,10 @@ struct mpcqp_engine {
   int* order_mem = nullptr;   // dispatch order of the fast path: [32 header ints: class counters, queue head | ORDER_BUCKETS x order_cap indices]
   int order_cap = 0;
   int slots = 0;              // workgroups the device holds at once (2 per CU)
+  double* wr_K = nullptr;     // wrench-space engine (mpcqp_wrench.h): K_q [6][N][N], K^-1 in tile layout (fp32 / fp64)
+  float* wr_kinv32 = nullptr;
+  double* wr_kinv64 = nullptr;
+  bool wrench_ok = false;     // the configuration admits the wrench-space form (isotropic omega weight, positive velocity weights)
   float* dual_mem = nullptr;  // warm-started engines: multipliers of the previous solve per batch slot [dual_cap][200]
   int64_t dual_cap = 0;
   bool timed = false;
@@ -90,22 +95,12 @@ hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* 
   dim3 grid((unsigned)B);
   OrderBuf ob = {nullptr, nullptr, 0, nullptr};
   // dispatch order (mpcqp_fast.h): worth a pre-pass as soon as the batch oversubscribes the workgroup slots
-  if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && e->slots > 0 && B > (int64_t)e->slots) {
-    if (e->order_cap < B) {   // grows with the largest batch seen; the old buffer may still be in use by queued work
-      int* mem = nullptr;
-      const int64_t cap = ((B + 1023) / 1024) * 1024;
-      if (hipMalloc(&mem, (size_t)(32 + ORDER_BUCKETS * cap) * sizeof(int)) == hipSuccess) {
-        if (e->order_mem) { (void)hipDeviceSynchronize(); (void)hipFree(e->order_mem); }
-        e->order_mem = mem; e->order_cap = (int)cap;
-      }
-    }
-    if (e->order_cap >= B) {
-      ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 32; ob.cap = e->order_cap;
-      hipError_t he = hipMemsetAsync(ob.cnt, 0, 32 * sizeof(int), s);
-      if (he != hipSuccess) return he;
-      hipLaunchKernelGGL((mpcqp_order_kernel<TIO, GAIT>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
-      grid = dim3((unsigned)(B < e->slots ? B : e->slots));   // queued form: resident workgroups pull QPs
-    }
+  if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && e->slots > 0 && B > (int64_t)e->slots && e->order_cap >= B) {
+    ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 32; ob.cap = e->order_cap;
+    hipError_t he = hipMemsetAsync(ob.cnt, 0, 32 * sizeof(int), s);
+    if (he != hipSuccess) return he;
+    hipLaunchKernelGGL((mpcqp_order_kernel<TIO, GAIT>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
+    grid = dim3((unsigned)(B < e->slots ? B : e->slots));   // queued form: resident workgroups pull QPs
   }
   if (e->cfg.precision == MPCQP_PREC_MIXED)
     hipLaunchKernelGGL((mpcqp_fast_solve<double, TIO, GAIT>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
@@ -116,18 +111,70 @@ hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* 
   return hipGetLastError();
 }
 
-// The per-slot multiplier record of a warm-started engine (grown to the largest batch seen; new slots start at zero = none).
-float* warm_duals(mpcqp_engine* e, int64_t B) {
-  if (!(e->cfg.flags & MPCQP_FLAG_WARM_START)) return nullptr;
-  if (e->dual_cap < B) {
+// Wrench-space engine (mpcqp_wrench.h): one QP per wave (horizon 10), 2 waves per SIMD = 8 resident workgroups per CU.
+template <typename TIO, bool GAIT>
+hipError_t launch_wrench(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
+                         float* res, hipStream_t s) {
+  constexpr int N = 10;
+  dim3 grid((unsigned)B);
+  OrderBuf ob = {nullptr, nullptr, 0, nullptr};
+  const int64_t slots = 4 * (int64_t)e->slots;   // e->slots = 2 per CU
+  if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && slots > 0 && B > slots && e->order_cap >= B) {
+    ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 32; ob.cap = e->order_cap;
+    hipError_t he = hipMemsetAsync(ob.cnt, 0, 32 * sizeof(int), s);
+    if (he != hipSuccess) return he;
+    hipLaunchKernelGGL((mpcqp_order_kernel<TIO, GAIT>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
+    grid = dim3((unsigned)slots);
+  }
+  const WrTabs tabs = {e->wr_K, e->wr_kinv32, e->wr_kinv64};
+  if (e->cfg.precision == MPCQP_PREC_MIXED)
+    hipLaunchKernelGGL((mpcqp_wrench_solve<double, float, double, TIO, N, GAIT>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
+                       (TIO*)X, st, it, res, ob, (int)B);
+  else
+    hipLaunchKernelGGL((mpcqp_wrench_solve<double, double, double, TIO, N, GAIT>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
+                       (TIO*)X, st, it, res, ob, (int)B);
+  return hipGetLastError();
+}
+
+// Workspace that depends on the batch size: the dispatch-order buffer of the queued launch forms and, for warm-started
+// engines, the per-slot multiplier record.  Sized by mpcqp_reserve(); a solve at a larger B than reserved grows them on the
+// spot (a device-wide synchronisation + allocation -- the only ones a solve can make, and only the first time).
+int reserve_workspace(mpcqp_engine* e, int64_t B) {
+  if (B <= 0) return MPCQP_OK;
+  if (e->order_cap < B) {
+    int* mem = nullptr;
+    const int64_t cap = ((B + 1023) / 1024) * 1024;
+    if (hipMalloc(&mem, (size_t)(32 + ORDER_BUCKETS * cap) * sizeof(int)) == hipSuccess) {
+      if (e->order_mem) { (void)hipDeviceSynchronize(); (void)hipFree(e->order_mem); }   // queued work may still read the old one
+      e->order_mem = mem; e->order_cap = (int)cap;
+    } else {
+      (void)hipGetLastError();   // tolerated: the batch runs in natural order; do not leave the error for the launch check
+    }
+  }
+  if ((e->cfg.flags & MPCQP_FLAG_WARM_START) && e->dual_cap < B) {
     float* mem = nullptr;
-    if (hipMalloc(&mem, (size_t)B * 200 * sizeof(float)) != hipSuccess) return e->dual_cap >= B ? e->dual_mem : nullptr;
+    if (hipMalloc(&mem, (size_t)B * 200 * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return MPCQP_ENOMEM; }
     (void)hipDeviceSynchronize();
-    (void)hipMemset(mem, 0, (size_t)B * 200 * sizeof(float));
+    (void)hipMemset(mem, 0, (size_t)B * 200 * sizeof(float));   // new slots start at zero = no record
     if (e->dual_mem) { (void)hipMemcpy(mem, e->dual_mem, (size_t)e->dual_cap * 200 * sizeof(float), hipMemcpyDeviceToDevice); (void)hipFree(e->dual_mem); }
     e->dual_mem = mem; e->dual_cap = B;
   }
-  return e->dual_mem;
+  return MPCQP_OK;
+}
+
+// Every entry point runs on the handle's device whatever the caller's current device is, and puts that one back.
+struct DeviceGuard {
+  int prev = -1; bool switched = false; hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+bool wrench_path_applies(const mpcqp_engine* h) {
+  return h->wrench_ok && h->cfg.N == 10 && h->cfg.precision != MPCQP_PREC_F32 && (h->cfg.flags & MPCQP_FLAG_POLISH) &&
+         !(h->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL | MPCQP_FLAG_WARM_START)) && h->cfg.alpha > 0.0;
 }
 
 bool fast_path_applies(const mpcqp_engine* h) {
@@ -149,6 +196,85 @@ hipError_t launch_prec(const mpcqp_engine* e, int64_t B, const void* x0, const v
 }
 
 }  // namespace
+
+// Inverse of a small SPD matrix by Gauss-Jordan with partial pivoting (host, fp64); returns false when singular.
+static bool invert_small(int n, const double* A, double* Ai) {
+  double* M = new (std::nothrow) double[2 * n * n];
+  if (!M) return false;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) { M[i * 2 * n + j] = A[i * n + j]; M[i * 2 * n + n + j] = i == j ? 1.0 : 0.0; }
+  bool ok = true;
+  for (int k = 0; k < n && ok; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < n; ++i) if (fabs(M[i * 2 * n + k]) > fabs(M[piv * 2 * n + k])) piv = i;
+    if (!(fabs(M[piv * 2 * n + k]) > 0)) { ok = false; break; }
+    if (piv != k) for (int j = 0; j < 2 * n; ++j) { const double t = M[k * 2 * n + j]; M[k * 2 * n + j] = M[piv * 2 * n + j]; M[piv * 2 * n + j] = t; }
+    const double p = 1.0 / M[k * 2 * n + k];
+    for (int j = 0; j < 2 * n; ++j) M[k * 2 * n + j] *= p;
+    for (int i = 0; i < n; ++i) {
+      if (i == k) continue;
+      const double f = M[i * 2 * n + k];
+      if (f != 0) for (int j = 0; j < 2 * n; ++j) M[i * 2 * n + j] -= f * M[k * 2 * n + j];
+    }
+  }
+  if (ok) for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Ai[i * n + j] = M[i * 2 * n + n + j];
+  delete[] M;
+  return ok;
+}
+
+// Tables of the wrench-space engine (mpcqp_wrench.h): K_q = 2 (wP_q c1 + wQ_q c0) and its inverse, the latter laid out as
+// the 8 x 8 register tiles of the G x G lane grid.  Returns false when the configuration does not admit the form.
+template <int N>
+static bool build_wrench_tables(mpcqp_engine* e, const double* tab /* c0 | c1 */) {
+  const MpcQpConfig& c = e->cfg;
+  if (c.w[6] != c.w[7]) return false;                       // omega weight must be isotropic in x, y (K block diagonal in q)
+  for (int i = 6; i < 12; ++i) if (!(c.w[i] > 0)) return false;   // K_q positive definite
+  constexpr int NT = WG<N>::NT, G = WG<N>::G, NQ = WG<N>::NQ;
+  double* K = new (std::nothrow) double[6 * N * N];
+  double* Ki = new (std::nothrow) double[6 * N * N];
+  float* t32 = new (std::nothrow) float[64 * NT];
+  double* t64 = new (std::nothrow) double[64 * NT];
+  bool ok = K && Ki && t32 && t64;
+  for (int q = 0; q < 6 && ok; ++q) {
+    for (int i = 0; i < N * N; ++i) K[q * N * N + i] = 2.0 * (c.w[q] * tab[N * N + i] + c.w[6 + q] * tab[i]);
+    ok = invert_small(N, K + q * N * N, Ki + q * N * N);
+  }
+  if (ok) {
+    for (int tid = 0; tid < NT; ++tid) {
+      const int gr = tid / G, gc = tid % G;
+      for (int r = 0; r < 8; ++r)
+        for (int cc = 0; cc < 8; ++cc) {
+          const int R = 8 * gr + r, C = 8 * gc + cc;
+          double v = 0.0;
+          if (R < NQ && C < NQ && R % 6 == C % 6) v = Ki[(R % 6) * N * N + (R / 6) * N + (C / 6)];
+          t64[(size_t)(8 * r + cc) * NT + tid] = v;
+          t32[(size_t)(8 * r + cc) * NT + tid] = (float)v;
+        }
+    }
+    hipError_t he = hipMalloc((void**)&e->wr_K, sizeof(double) * 6 * N * N);
+    if (he == hipSuccess) he = hipMemcpy(e->wr_K, K, sizeof(double) * 6 * N * N, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMalloc((void**)&e->wr_kinv32, sizeof(float) * 64 * NT);
+    if (he == hipSuccess) he = hipMemcpy(e->wr_kinv32, t32, sizeof(float) * 64 * NT, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMalloc((void**)&e->wr_kinv64, sizeof(double) * 64 * NT);
+    if (he == hipSuccess) he = hipMemcpy(e->wr_kinv64, t64, sizeof(double) * 64 * NT, hipMemcpyHostToDevice);
+    if (he != hipSuccess) { (void)hipGetLastError(); ok = false; }
+  }
+  delete[] K; delete[] Ki; delete[] t32; delete[] t64;
+  return ok;
+}
+
+static void free_engine(mpcqp_engine* h) {
+  if (h->ctab) (void)hipFree(h->ctab);
+  if (h->dcfg) (void)hipFree(h->dcfg);
+  if (h->order_mem) (void)hipFree(h->order_mem);
+  if (h->dual_mem) (void)hipFree(h->dual_mem);
+  if (h->wr_K) (void)hipFree(h->wr_K);
+  if (h->wr_kinv32) (void)hipFree(h->wr_kinv32);
+  if (h->wr_kinv64) (void)hipFree(h->wr_kinv64);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+}
 
 extern "C" {
 
@@ -186,7 +312,7 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   e->err[0] = 0;
   e->cfg = *cfg;
   const int N = cfg->N;
-  auto reject = [&](int code) { delete e; return code; };
+  auto reject = [&](int code) { free_engine(e); return code; };
   if (!(N == 10 || N == 20)) return reject(MPCQP_EINVAL);
   if (cfg->precision < MPCQP_PREC_F32 || cfg->precision > MPCQP_PREC_F64) return reject(MPCQP_EINVAL);
   if (cfg->precision == MPCQP_PREC_F64 && N != 10) return reject(MPCQP_EINVAL);
@@ -203,8 +329,9 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return reject(MPCQP_ENODEV);
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return reject(MPCQP_ENODEV);  // gfx950 code objects only
-  e->slots = 2 * prop.multiProcessorCount;   // the fast path's 256-VGPR, 3-wave workgroups: two per CU
-  if (hipSetDevice(cfg->device) != hipSuccess) return reject(MPCQP_EHIP);
+  e->slots = 2 * prop.multiProcessorCount;   // the tile kernel's 256-VGPR, 3-wave workgroups: two per CU
+  DeviceGuard guard(cfg->device);            // the caller's current device is restored on return
+  if (guard.err != hipSuccess) return reject(MPCQP_EHIP);
 
   DevCfg& d = e->dev;
   d.delta = cfg->delta; d.inv_m = 1.0 / cfg->m;
@@ -232,35 +359,34 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
     }
   hipError_t he = hipMalloc((void**)&e->ctab, sizeof(double) * 2 * N * N);
   if (he == hipSuccess) he = hipMemcpy(e->ctab, tab, sizeof(double) * 2 * N * N, hipMemcpyHostToDevice);
+  if (he == hipSuccess && N == 10) e->wrench_ok = build_wrench_tables<10>(e, tab);
   delete[] tab;
   if (he == hipSuccess) he = hipMalloc((void**)&e->dcfg, sizeof(DevCfg));
   if (he == hipSuccess) he = hipMemcpy(e->dcfg, &e->dev, sizeof(DevCfg), hipMemcpyHostToDevice);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);
-  if (he != hipSuccess) {
-    if (e->ctab) (void)hipFree(e->ctab);
-    if (e->dcfg) (void)hipFree(e->dcfg);
-    if (e->ev0) (void)hipEventDestroy(e->ev0);
-    if (e->ev1) (void)hipEventDestroy(e->ev1);
-    return reject(MPCQP_EHIP);
-  }
+  if (he != hipSuccess) return reject(MPCQP_EHIP);
   *out = e;
   return MPCQP_OK;
 }
 
 int mpcqp_destroy(mpcqp_handle h) {
   if (!h) return MPCQP_OK;
-  if (h->ctab) (void)hipFree(h->ctab);
-  if (h->dcfg) (void)hipFree(h->dcfg);
-  if (h->order_mem) (void)hipFree(h->order_mem);
-  if (h->dual_mem) (void)hipFree(h->dual_mem);
-  if (h->ev0) (void)hipEventDestroy(h->ev0);
-  if (h->ev1) (void)hipEventDestroy(h->ev1);
-  delete h;
+  DeviceGuard guard(h->cfg.device);
+  free_engine(h);
   return MPCQP_OK;
 }
 
 const char* mpcqp_last_error(mpcqp_handle h) { return h ? h->err : "null handle"; }
+
+int mpcqp_reserve(mpcqp_handle h, int64_t B) {
+  if (!h) return MPCQP_EINVAL;
+  if (B < 0 || B > 0x7fffffff) return fail(h, MPCQP_EINVAL, "mpcqp_reserve: batch size out of range");
+  DeviceGuard guard(h->cfg.device);
+  if (guard.err != hipSuccess) return fail(h, MPCQP_EHIP, "hipSetDevice", guard.err);
+  const int rc = reserve_workspace(h, B);
+  return rc == MPCQP_OK ? rc : fail(h, rc, "mpcqp_reserve: workspace allocation failed");
+}
 
 int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, const uint8_t* contact, const void* xdes,
                       const void* mu, void* u_out, void* X_out, int32_t* status, int32_t* iters, float* res, void* stream) {
@@ -268,23 +394,28 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
   if (B < 0 || B > 0x7fffffff) return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch: batch size out of range");
   if (B > 0 && (!x0 || !r || !contact || !xdes || !mu || !u_out || !status || !iters))
     return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch: null buffer");
+  DeviceGuard guard(h->cfg.device);
+  if (guard.err != hipSuccess) return fail(h, MPCQP_EHIP, "hipSetDevice", guard.err);
   hipStream_t st = (hipStream_t)stream;
   hipError_t he = hipSuccess;
-  const bool fast = fast_path_applies(h);
+  const bool wrench = wrench_path_applies(h), fast = !wrench && fast_path_applies(h);
   const bool warm = (h->cfg.flags & MPCQP_FLAG_WARM_START) != 0;   // u_out is read as the initial guess first
-  float* ys = (warm && fast && B > 0) ? warm_duals(h, B) : nullptr;
+  if ((wrench || fast) && reserve_workspace(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_solve_batch: workspace allocation failed");
+  float* ys = (warm && fast && B > 0) ? h->dual_mem : nullptr;
   const int shift = (h->cfg.flags & MPCQP_FLAG_WARM_SHIFT) ? 1 : 0;
   he = hipEventRecord(h->ev0, st);
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
-  if (B > 0 && fast) {
+  if (B > 0 && (wrench || fast)) {
     if (h->cfg.dtype == MPCQP_DTYPE_F64) {
       const FastIn<double> in = {(const double*)x0, (const double*)r, contact, (const double*)xdes, (const double*)mu,
                                  nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const double*)u_out : nullptr, ys, shift};
-      he = launch_fast<double, false>(h, B, in, u_out, X_out, status, iters, res, st);
+      he = wrench ? launch_wrench<double, false>(h, B, in, u_out, X_out, status, iters, res, st)
+                  : launch_fast<double, false>(h, B, in, u_out, X_out, status, iters, res, st);
     } else {
       const FastIn<float> in = {(const float*)x0, (const float*)r, contact, (const float*)xdes, (const float*)mu,
                                 nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const float*)u_out : nullptr, ys, shift};
-      he = launch_fast<float, false>(h, B, in, u_out, X_out, status, iters, res, st);
+      he = wrench ? launch_wrench<float, false>(h, B, in, u_out, X_out, status, iters, res, st)
+                  : launch_fast<float, false>(h, B, in, u_out, X_out, status, iters, res, st);
     }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
   } else if (B > 0) {
@@ -310,11 +441,15 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
   if (B < 0 || B > 0x7fffffff) return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: batch size out of range");
   if (B > 0 && (!x0 || !ref || !feet0 || !footholds || !gait || !feet_id || !mu || !u_out || !status || !iters))
     return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: null buffer");
-  if (!fast_path_applies(h))
-    return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: needs N = 10, MIXED or F32 precision, polish, alpha > 0");
+  const bool wrench = wrench_path_applies(h);
+  if (!wrench && !fast_path_applies(h))
+    return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: needs N = 10, polish, alpha > 0 (and MIXED or F32 precision on the tile kernel)");
+  DeviceGuard guard(h->cfg.device);
+  if (guard.err != hipSuccess) return fail(h, MPCQP_EHIP, "hipSetDevice", guard.err);
   hipStream_t st = (hipStream_t)stream;
   const bool warm = (h->cfg.flags & MPCQP_FLAG_WARM_START) != 0;
-  float* ys = (warm && B > 0) ? warm_duals(h, B) : nullptr;
+  if (reserve_workspace(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_solve_batch_gait: workspace allocation failed");
+  float* ys = (warm && B > 0) ? h->dual_mem : nullptr;
   const int shift = (h->cfg.flags & MPCQP_FLAG_WARM_SHIFT) ? 1 : 0;
   hipError_t he = hipEventRecord(h->ev0, st);
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
@@ -323,12 +458,14 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
       const FastIn<double> in = {(const double*)x0, nullptr, nullptr, nullptr, (const double*)mu, (const double*)ref,
                                  (const double*)feet0, (const double*)footholds, gait, feet_id,
                                  warm ? (const double*)u_out : nullptr, ys, shift};
-      he = launch_fast<double, true>(h, B, in, u_out, X_out, status, iters, res, st);
+      he = wrench ? launch_wrench<double, true>(h, B, in, u_out, X_out, status, iters, res, st)
+                  : launch_fast<double, true>(h, B, in, u_out, X_out, status, iters, res, st);
     } else {
       const FastIn<float> in = {(const float*)x0, nullptr, nullptr, nullptr, (const float*)mu, (const float*)ref,
                                 (const float*)feet0, (const float*)footholds, gait, feet_id,
                                 warm ? (const float*)u_out : nullptr, ys, shift};
-      he = launch_fast<float, true>(h, B, in, u_out, X_out, status, iters, res, st);
+      he = wrench ? launch_wrench<float, true>(h, B, in, u_out, X_out, status, iters, res, st)
+                  : launch_fast<float, true>(h, B, in, u_out, X_out, status, iters, res, st);
     }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
   }
@@ -343,6 +480,8 @@ int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* u, const void* jac, 
   if (B < 0 || B > 0x1fffffff) return fail(h, MPCQP_EINVAL, "mpcqp_torque_map: batch size out of range");
   if (B > 0 && (!u || !jac || !tau)) return fail(h, MPCQP_EINVAL, "mpcqp_torque_map: null buffer");
   if (B == 0) return MPCQP_OK;
+  DeviceGuard guard(h->cfg.device);
+  if (guard.err != hipSuccess) return fail(h, MPCQP_EHIP, "hipSetDevice", guard.err);
   const dim3 grid((unsigned)((4 * B + 255) / 256));
   if (h->cfg.dtype == MPCQP_DTYPE_F64)
     hipLaunchKernelGGL((mpcqp_torque_kernel<double>), grid, dim3(256), 0, (hipStream_t)stream, (const double*)u, (const double*)jac,
@@ -358,6 +497,7 @@ int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* u, const void* jac, 
 int mpcqp_last_kernel_ms(mpcqp_handle h, float* ms) {
   if (!h || !ms) return MPCQP_EINVAL;
   if (!h->timed) return fail(h, MPCQP_EINVAL, "mpcqp_last_kernel_ms: no solve recorded");
+  DeviceGuard guard(h->cfg.device);
   hipError_t he = hipEventSynchronize(h->ev1);
   if (he == hipSuccess) he = hipEventElapsedTime(ms, h->ev0, h->ev1);
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventElapsedTime", he);

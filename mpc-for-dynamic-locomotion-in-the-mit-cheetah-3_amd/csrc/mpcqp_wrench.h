@@ -1,0 +1,1024 @@
+// mpcqp_wrench.h -- wrench-space engine: one QP per WAVE (horizon 10) or per four waves (horizon 20).
+//
+// The condensed Hessian of the reference QP (src/mpc.py:110-134) factors through the per-stage net wrench:
+//     H = 2 alpha I + T' K T,      T = blockdiag(T_j),  T_j (6 x 12): stage forces -> [Rz tau_j ; a_j]
+//     tau_j = sum_l Ihat^-1 (r_l x f_l)   (src/mpc.py:78,98-107),   a_j = sum_l c_l f_l / m
+//     K = (+)_{q<6} K_q,   K_q[j][j'] = 2 (wP_q c1[j][j'] + wQ_q c0[j][j'])      (N x N per wrench component)
+// with c0 = d^2 (N - max(j,j')), c1 = d^4 sum_{k>max(j,j')} (k-1-j+th)(k-1-j'+th) the same stage-pair tables the
+// closed-form tile build of mpcqp_fast.h uses, wP = w[0..5] (Theta, p), wQ = w[6..11] (omega, v).  In the Rz-rotated
+// angular coordinates K is block diagonal in q as long as the omega weight is isotropic in x,y (the reference's is,
+// src/mpc.py:128-130) -- and then K, K^-1 are CONSTANTS of the configuration, inverted once on the host in fp64.
+// Both linear systems of the solve are "diagonal + T'KT" (ADMM: D = 2 alpha + sigma + rho G'G; polish: the same on the
+// free variables), so by Woodbury
+//     M^-1 = D^-1 - D^-1 T' S^-1 T D^-1,      S = K^-1 + T D^-1 T'      (6N x 6N;  T D^-1 T' is block diagonal)
+// a 60 x 60 sweep instead of a 120 x 120 one (8 x fewer flops), a 60 x 60 mat-vec per ADMM iteration instead of a
+// 120 x 120 one, and an 8 x 8 register tile per lane on an 8 x 8 lane grid: one QP per wave, no workgroup barrier
+// anywhere in the horizon-10 solve (LDS traffic of a wave is in order), 2 waves per SIMD.
+// Precision: the explicit fp32 inverse of S is accurate enough for ADMM (whose job is the active set) but not for the
+// polish -- cond(S) reaches 1e6 there (K^-1 ~ 1e-3 next to T D^-1 T' ~ 1e3 with D = 2 alpha) and the error of S^-1 is
+// amplified by D^-1 T'T D^-1 (numpy study, tools/wrench_proto.py: the fp32 refinement diverges on half of the QPs).
+// The polish therefore builds and sweeps its S in fp64 (v_fma_f64 issues at the unpacked fp32 rate on gfx950): the
+// solve is then exact to ~1e-9 and no iterative refinement is needed (one solve + two gradients per step).
+#pragma once
+#include "mpcqp_fast.h"   // FastIn, OrderBuf, the dispatch-order pre-pass, DPP helpers
+
+namespace {
+
+template <int N_>
+struct WG {
+  static constexpr int N = N_, NL = 4 * N, n = 12 * N, NQ = 6 * N;
+  static constexpr int G = N <= 10 ? 8 : 16;      // lane grid G x G of 8 x 8 tiles
+  static constexpr int NT = G * G, NW = NT / 64;
+  static constexpr int DP = 8 * G;                // padded wrench dimension
+  static constexpr int NB = (NQ + 7) / 8;         // pivot blocks
+  static_assert(NQ <= DP, "horizon too long for the lane grid");
+};
+
+// Constant tables of a configuration (device memory, built by mpcqp_create).
+struct WrTabs {
+  const double* K;        // [6][N][N]   K_q
+  const float* kinv32;    // [64][NT]    K^-1 in tile layout: element (r, c) of lane tid at [(8 r + c) * NT + tid]
+  const double* kinv64;   // [64][NT]
+};
+
+template <typename TV, int N>
+struct SmemW {
+  using Geo = WG<N>;
+  TV x0[13];
+  TV mu, cy, sy;
+  TV rzw0[3];
+  TV wP[6], wQ[6];
+  TV delta, theta, alpha, inv_m, fmin, fmax;
+  TV rr[Geo::n];                 // lever arms
+  TV Bl[Geo::NL * 9];            // per leg-stage: Rz Ihat^-1 [r]x, masked by contact (row i = angular component, col a = force axis)
+  TV cm[Geo::NL];                // contact / m
+  TV e0P[Geo::NQ], e0Q[Geo::NQ]; // free response - target, stage k = j + 1 at [6 j + q]: P = (Theta, p), Q = (Rz omega, v)
+  TV gam[Geo::NQ];               // gradient of the cost in wrench space at u = 0
+  TV gl[Geo::n];                 // linear term g = T' gam
+  TV uv[Geo::n], gv[Geo::n];     // point / gradient of the structured gradient
+  TV ww[Geo::NQ], kap[Geo::NQ];  // wrench of uv, K ww + gam
+  TV pu[Geo::n], py[Geo::NL * 5];
+  float ua[Geo::n], za[Geo::NL * 5], ya[Geo::NL * 5];   // last ADMM iterate (ya = multipliers, unscaled)
+  alignas(16) double E[N * 36];                          // T D^-1 T' blocks (TM-typed view)
+  alignas(16) double piv[2 * Geo::DP];                   // pivot-row broadcast (TM-typed view)
+  alignas(16) double bv[Geo::DP], cv[Geo::DP];           // mat-vec in / out (TM-typed view)
+  float red[Geo::NW * 4];
+  float kkt[4];
+  float gmax, rho, ratio;
+  int iters, psteps, hard, warm, bad;
+  uint8_t ct[Geo::NL];
+  uint8_t aset[Geo::NL];         // active set of the current polish step (ActSet code)
+};
+
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+template <int NW>
+__device__ __forceinline__ void wsync() {
+  if constexpr (NW == 1) {   // one wave: its LDS operations execute in order; only the compiler has to be told
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
+template <int Q, int NW>
+__device__ __forceinline__ void wmax(float (&v)[Q], float* red, int tid) {
+  if constexpr (NW == 1) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = wave_max(v[q]);
+  } else {
+    block_max<Q, NW>(v, red, tid);
+  }
+}
+
+template <typename T> __device__ __forceinline__ T quad_sum(T v) { v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); return v; }
+
+// Reduce-scatter of 8 values over the 8 lanes of a group: lane gc ends with the group total of element gc.
+template <typename T>
+__device__ __forceinline__ T rs8(const T (&v)[8], int gc) {
+  const bool hi = (gc & 4) != 0, b1 = (gc & 2) != 0, b0 = (gc & 1) != 0;
+  T t[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { const T keep = hi ? v[4 + m] : v[m], send = hi ? v[m] : v[4 + m]; t[m] = keep + dpp_mov<0x141>(send); }
+  T s2[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) { const T keep = b1 ? t[2 + m] : t[m], send = b1 ? t[m] : t[2 + m]; s2[m] = keep + dpp_mov<0x4E>(send); }
+  const T keep = b0 ? s2[1] : s2[0], send = b0 ? s2[0] : s2[1];
+  return keep + dpp_mov<0xB1>(send);
+}
+
+__device__ __forceinline__ float w_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double w_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// ----------------------------------------------------------------------------------------------------- register tile
+template <typename TM> struct WTile;
+template <> struct WTile<float> { f2 v[8][4]; };
+template <> struct WTile<double> { double v[8][8]; };
+
+__device__ __forceinline__ float tget(const WTile<float>& t, int i, int j) { return (j & 1) ? t.v[i][j >> 1].y : t.v[i][j >> 1].x; }
+__device__ __forceinline__ double tget(const WTile<double>& t, int i, int j) { return t.v[i][j]; }
+__device__ __forceinline__ void tset(WTile<float>& t, int i, int j, float x) { if (j & 1) t.v[i][j >> 1].y = x; else t.v[i][j >> 1].x = x; }
+__device__ __forceinline__ void tset(WTile<double>& t, int i, int j, double x) { t.v[i][j] = x; }
+
+template <typename TM> __device__ __forceinline__ void ld8(const TM* p, TM (&o)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[8]) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<double>(const double* p, double (&o)[8]) {
+#pragma unroll
+  for (int h = 0; h < 4; ++h) { const double2 a = reinterpret_cast<const double2*>(p)[h]; o[2 * h] = a.x; o[2 * h + 1] = a.y; }
+}
+template <typename TM> __device__ __forceinline__ void st8(TM* p, const TM (&o)[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&o)[8]) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(o[0], o[1], o[2], o[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(o[4], o[5], o[6], o[7]);
+}
+template <> __device__ __forceinline__ void st8<double>(double* p, const double (&o)[8]) {
+#pragma unroll
+  for (int h = 0; h < 4; ++h) reinterpret_cast<double2*>(p)[h] = make_double2(o[2 * h], o[2 * h + 1]);
+}
+
+// Opaque redefinition of the whole tile (no instructions): arithmetic on the tile cannot move across this point.
+__device__ __forceinline__ void tpin(WTile<float>& t) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(t.v[i][0]), "+v"(t.v[i][1]), "+v"(t.v[i][2]), "+v"(t.v[i][3]));
+}
+__device__ __forceinline__ void tpin(WTile<double>& t) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    asm volatile("" : "+v"(t.v[i][0]), "+v"(t.v[i][1]), "+v"(t.v[i][2]), "+v"(t.v[i][3]), "+v"(t.v[i][4]), "+v"(t.v[i][5]), "+v"(t.v[i][6]), "+v"(t.v[i][7]));
+}
+
+// tile[i][j] -= m[i] * vc[j]
+__device__ __forceinline__ void rank1(WTile<float>& t, const float (&m)[8], const float (&vc)[8]) {
+  f2 c2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c2[j] = mk2(vc[2 * j], vc[2 * j + 1]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f2 mi = splat2(-m[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.v[i][j] = __builtin_elementwise_fma(mi, c2[j], t.v[i][j]);
+  }
+}
+__device__ __forceinline__ void rank1(WTile<double>& t, const double (&m)[8], const double (&vc)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const double mi = -m[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t.v[i][j] = fma(mi, vc[j], t.v[i][j]);
+  }
+}
+// acc[i] = sum_j tile[i][j] x[j]
+__device__ __forceinline__ void tilemv(const WTile<float>& t, const float (&x)[8], float (&acc)[8]) {
+  f2 x2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x2[j] = mk2(x[2 * j], x[2 * j + 1]);
+  f2 a[8];   // eight independent chains, column-major order (back-to-back dependent packed FMAs cost a wait state each)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = t.v[i][0] * x2[0];
+#pragma unroll
+  for (int j = 1; j < 4; ++j) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = __builtin_elementwise_fma(t.v[i][j], x2[j], a[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = a[i].x + a[i].y;
+}
+__device__ __forceinline__ void tilemv(const WTile<double>& t, const double (&x)[8], double (&acc)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = t.v[i][0] * x[0];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fma(t.v[i][j], x[j], acc[i]);
+  }
+}
+
+// tile <- K^-1 (constant, tile layout in global memory) + E (block diagonal, 6 x 6 per stage, in LDS).
+template <typename TM, int N>
+__device__ __forceinline__ void w_tile_init(WTile<TM>& t, const TM* __restrict__ kinvT, const TM* __restrict__ E, int gr, int gc, int tid) {
+  constexpr int NT = WG<N>::NT, NQ = WG<N>::NQ;
+  // (opaque copies: the index arithmetic below is invariant across the QPs of a resident wave, and hoisted out of the QP
+  //  loop its ~200 masks and addresses would occupy -- and spill -- registers for the whole kernel)
+  asm volatile("" : "+v"(gr), "+v"(gc), "+v"(tid));
+  int cst[8], cof[8];   // stage / offset-in-stage of my eight columns
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { const int C = 8 * gc + c; cst[c] = C / 6; cof[c] = C - 6 * cst[c]; }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    asm volatile("" ::: "memory");   // one row's loads in flight at a time (the tile itself is most of the register file in fp64)
+    const int R = 8 * gr + r, jR = R / 6, qR = R - 6 * jR;
+    const int base = 36 * jR + 6 * qR;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const bool in = (cst[c] == jR) && (R < NQ);
+      const TM e = E[in ? base + cof[c] : 0];
+      const TM k = kinvT[(size_t)(8 * r + c) * NT + tid];
+      tset(t, r, c, k + (in ? e : (TM)0));
+    }
+  }
+}
+
+// In-register symmetric sweep of all NQ pivots: tile <- -S^-1.  Lanes of grid row og publish pivot row k = 8 og + rr; by
+// symmetry the same vector serves as the pivot column.  One LDS broadcast per pivot; no barrier when the QP is one wave.
+template <typename TM, int N>
+__device__ __forceinline__ void w_sweep(WTile<TM>& t, TM* __restrict__ piv, int gr, int gc) {
+  constexpr int NQ = WG<N>::NQ, NW = WG<N>::NW, DP = WG<N>::DP, NB = WG<N>::NB;
+  int step = 0;
+  for (int og = 0; og < NB; ++og) {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      if (8 * og + rr >= NQ) break;   // uniform
+      TM* vb = piv + (NW > 1 ? (step & 1) * DP : 0);
+      if (gr == og) {
+        TM row[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = tget(t, rr, j);
+        st8<TM>(vb + 8 * gc, row);
+      }
+      wsync<NW>();
+      const TM p = w_rcp(vb[8 * og + rr]);
+      TM vc[8], vr[8];
+      ld8<TM>(vb + 8 * gc, vc);
+      ld8<TM>(vb + 8 * gr, vr);
+      const bool prow = gr == og, pcol = gc == og;
+      TM m[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { vr[i] *= p; m[i] = vr[i]; }
+      // the owner's pivot row becomes p * row: its tile row IS the published row, so the multiplier 1 - p does it
+      m[rr] = prow ? (TM)1 - p : vr[rr];
+      rank1(t, m, vc);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {   // pivot column (selects: a divergent region that writes the tile makes the compiler copy it)
+        const TM v = (i == rr && prow) ? -p : vr[i];
+        tset(t, i, rr, pcol ? v : tget(t, i, rr));
+      }
+      if constexpr (NW == 1) wsync<1>();   // the next pivot's publication must not overtake this pivot's reads (compiler order only)
+      // Keep the pivots apart: left alone, the optimiser pipelines several pivots (publishes the next row early, defers the
+      // rest of the rank-1 updates), which keeps two or three pivots' row / column vectors alive next to the tile and spills
+      // inside the loop.
+      tpin(t);
+      ++step;
+    }
+  }
+}
+
+// y = S^-1 x for x in LDS (bv, padded layout): returns element 8 gr + gc (valid on lanes gc < 8) and writes it to cv.
+template <typename TM, int N>
+__device__ __forceinline__ void w_matvec(const WTile<TM>& t, const TM* __restrict__ bv, TM* __restrict__ cv, int gr, int gc) {
+  constexpr int G = WG<N>::G;
+  TM x[8], acc[8];
+  ld8<TM>(bv + 8 * gc, x);
+  tilemv(t, x, acc);
+  if constexpr (G == 16) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += dpp_mov<0x140>(acc[i]);   // row_mirror: both halves of the 16 now hold the pair sums
+  }
+  const TM tot = -rs8<TM>(acc, gc & 7);   // tile = -S^-1
+  if (gc < 8) cv[8 * gr + gc] = tot;
+}
+
+// Per-leg data of a linear solve with M = D + A-stack' K A-stack: columns of the 6 x 3 wrench map and the inverse diagonal.
+template <typename TM>
+struct LegSys {
+  TM A[3][6];    // A[c][q]: wrench component q of reduced variable c
+  TM dinv[3];
+};
+
+// E_j = sum_legs A diag(dinv) A' -> LDS (full 6 x 6 per stage).  Leg lanes; ends with a sync.
+template <typename TM, int N>
+__device__ __forceinline__ void w_build_E(const LegSys<TM>& L, TM* __restrict__ E, int tid) {
+  constexpr int NL = WG<N>::NL, NW = WG<N>::NW;
+  TM e[21];
+  int k = 0;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+#pragma unroll
+    for (int p = q; p < 6; ++p) {
+      TM a = L.dinv[0] * L.A[0][q] * L.A[0][p];
+      a = fma(L.dinv[1] * L.A[1][q], L.A[1][p], a);
+      a = fma(L.dinv[2] * L.A[2][q], L.A[2][p], a);
+      e[k++] = quad_sum(a);
+    }
+  }
+  if (tid < NL && (tid & 3) == 0) {
+    TM* Ej = E + 36 * (tid >> 2);
+    k = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+      for (int p = q; p < 6; ++p) { Ej[6 * q + p] = e[k]; Ej[6 * p + q] = e[k]; ++k; }
+    }
+  }
+  wsync<NW>();
+}
+
+// x = M^-1 rhs through the swept tile: x = dinv (rhs - A' S^-1 A-stack dinv rhs).  All lanes call; leg lanes hold data.
+template <typename TM, int N>
+__device__ __forceinline__ void w_solve(const WTile<TM>& t, const LegSys<TM>& L, const TM (&rhs)[3], TM (&x)[3], TM* __restrict__ bv,
+                                        TM* __restrict__ cv, int tid, int gr, int gc) {
+  constexpr int NL = WG<N>::NL, NW = WG<N>::NW;
+  TM a[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a[c] = L.dinv[c] * rhs[c];
+  TM b[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) b[q] = quad_sum(fma(L.A[2][q], a[2], fma(L.A[1][q], a[1], L.A[0][q] * a[0])));
+  {   // lanes 0..2 of the quad write two components each (lane 3 repeats lane 2)
+    const int l = min(tid & 3, 2);
+    const TM v0 = l == 0 ? b[0] : (l == 1 ? b[2] : b[4]), v1 = l == 0 ? b[1] : (l == 1 ? b[3] : b[5]);
+    if (tid < NL) { TM* d = bv + 6 * (tid >> 2) + 2 * l; d[0] = v0; d[1] = v1; }
+  }
+  wsync<NW>();
+  w_matvec<TM, N>(t, bv, cv, gr, gc);
+  wsync<NW>();
+  const TM* cj = cv + 6 * (min(tid, NL - 1) >> 2);
+  TM c6[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) c6[q] = cj[q];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    TM s = L.A[c][0] * c6[0];
+#pragma unroll
+    for (int q = 1; q < 6; ++q) s = fma(L.A[c][q], c6[q], s);
+    x[c] = a[c] - L.dinv[c] * s;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------- inputs
+template <typename TIO, bool GAIT>
+__device__ __forceinline__ double w_xdes(const FastIn<TIO>& in, double delta, size_t b, int N, int k, int c) {
+  if constexpr (!GAIT) {
+    return (double)in.xdes[b * (size_t)(N + 1) * 13 + k * 13 + c];
+  } else {   // src/mpc.py:202-214
+    const TIO* ref = in.ref + b * 10;
+    if (c < 2) return (double)ref[c];
+    if (c == 2) return (double)ref[2] + (double)k * delta * (double)ref[9];
+    if (c < 6) return (double)ref[c] + (double)k * delta * (double)ref[6 + (c - 3)];
+    if (c < 8) return 0.0;
+    if (c == 8) return (double)ref[9];
+    if (c < 12) return (double)ref[6 + (c - 9)];
+    return (double)in.x0[b * 13 + 12];
+  }
+}
+
+// Operator tuple / gait descriptors -> LDS (x0, lever arms, contact, mu); returns the per-thread non-finite flag.
+template <typename TV, typename TIO, int N, bool GAIT>
+__device__ __forceinline__ int w_load(SmemW<TV, N>& s, const FastIn<TIO>& in, const DevCfg& cfg, size_t b, int tid) {
+  constexpr int NT = WG<N>::NT, n = WG<N>::n, NL = WG<N>::NL;
+  int bad = 0;
+  for (int i = tid; i < 13; i += NT) { const TV v = (TV)in.x0[b * 13 + i]; s.x0[i] = v; bad |= !isfinite(v); }
+  for (int i = tid; i < (N + 1) * 13; i += NT) bad |= !isfinite(w_xdes<TIO, GAIT>(in, cfg.delta, b, N, i / 13, i % 13));
+  if constexpr (!GAIT) {
+    for (int i = tid; i < n; i += NT) { const TV v = (TV)in.r[b * n + i]; s.rr[i] = v; bad |= !isfinite(v); }
+    for (int i = tid; i < NL; i += NT) s.ct[i] = in.contact[b * NL + i] ? 1 : 0;
+  } else {   // src/mpc.py:218-254 with the planner queries of src/footstep_planner.py:226-246 (see fast_load_gait)
+    const TV d = (TV)cfg.delta;
+    const int tis = in.gait[b * 4 + 0], ss = in.gait[b * 4 + 1], ds = in.gait[b * 4 + 2];
+    const TIO* ref = in.ref + b * 10;
+    for (int i = tid; i < n; i += NT) {
+      const int k = i / 12, l = (i % 12) / 3, a = i % 3;
+      int tau = tis + k, st = 0;
+      if (tau >= ss + ds) { tau -= ss + ds; st = 1; }
+      TV v;
+      if (k == 0) v = (TV)in.feet0[b * 12 + l * 3 + a] - (TV)in.x0[b * 13 + 3 + a];
+      else v = (TV)in.footholds[b * 24 + st * 12 + l * 3 + a] - ((TV)ref[3 + a] + (TV)k * d * (TV)ref[6 + a]);
+      s.rr[i] = v;
+      bad |= !isfinite(v);
+      if (a == 0) s.ct[k * 4 + l] = (tau < ss) ? (in.feet_id[b * 8 + st * 4 + l] ? 1 : 0) : 1;
+    }
+  }
+  if (tid == 0) { const TV m = (TV)in.mu[b]; s.mu = m; bad |= !isfinite(m); }
+  return bad;
+}
+
+// Structured gradient at s.uv: s.gv = 2 alpha u + T'(K T u + gam).  Leaves the wrench in s.ww.  Needs s.uv visible; the
+// caller's leg gradient is also returned in registers.  Ends with a sync.
+template <typename TV, int N>
+__device__ __forceinline__ void w_grad(SmemW<TV, N>& s, const double* __restrict__ Ktab, int tid, TV (&gr)[3]) {
+  constexpr int NL = WG<N>::NL, NQ = WG<N>::NQ, NW = WG<N>::NW, NT = WG<N>::NT;
+  const int L = min(tid, NL - 1);
+  TV f[3], B[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) f[a] = s.uv[3 * L + a];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) B[i] = s.Bl[9 * L + i];
+  const TV cm = s.cm[L];
+  {
+    TV w6[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w6[i] = quad_sum(fma(B[3 * i + 2], f[2], fma(B[3 * i + 1], f[1], B[3 * i] * f[0])));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) w6[3 + a] = quad_sum(cm * f[a]);
+    if (tid < NL && (tid & 3) == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) s.ww[6 * (tid >> 2) + q] = w6[q];
+    }
+  }
+  wsync<NW>();
+  for (int e = tid; e < NQ; e += NT) {
+    const int j = e / 6, q = e - 6 * j;
+    const double* Kr = Ktab + ((size_t)q * N + j) * N;
+    TV acc = s.gam[e];
+#pragma unroll
+    for (int jp = 0; jp < N; ++jp) acc = fma((TV)Kr[jp], s.ww[6 * jp + q], acc);
+    s.kap[e] = acc;
+  }
+  wsync<NW>();
+  {
+    const TV* kj = s.kap + 6 * (L >> 2);
+    const TV a2 = (TV)2 * s.alpha;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      TV g = fma(a2, f[a], cm * kj[3 + a]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) g = fma(B[3 * i + a], kj[i], g);
+      gr[a] = g;
+      if (tid < NL) s.gv[3 * L + a] = g;
+    }
+  }
+  wsync<NW>();
+}
+
+// Per-QP setup: constants (once per workgroup), inputs, B_l, free response, gam, g, |g|_inf, cold ADMM state.
+template <typename TV, typename TIO, int N, bool GAIT>
+__device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const WrTabs& tabs, const FastIn<TIO>& in, size_t b, int tid,
+                                       bool first) {
+  constexpr int NT = WG<N>::NT, NL = WG<N>::NL, NQ = WG<N>::NQ, n = WG<N>::n, NW = WG<N>::NW, DP = WG<N>::DP;
+  if (first) {
+    if (tid < 6) { s.wP[tid] = (TV)cfg.w[tid]; s.wQ[tid] = (TV)cfg.w[6 + tid]; }
+    if (tid == 0) {
+      s.delta = (TV)cfg.delta; s.theta = (TV)cfg.theta; s.alpha = (TV)cfg.alpha; s.inv_m = (TV)cfg.inv_m;
+      s.fmin = (TV)cfg.fmin; s.fmax = (TV)cfg.fmax;
+    }
+    for (int i = tid; i < DP; i += NT) { s.bv[i] = 0.0; s.cv[i] = 0.0; s.piv[i] = 0.0; s.piv[DP + i] = 0.0; }   // pad slots stay finite
+  }
+  int bad = w_load<TV, TIO, N, GAIT>(s, in, cfg, b, tid);
+  if constexpr (NW == 1) {
+    bad = __any(bad) ? 1 : 0;
+  } else {
+    bad = __syncthreads_or(bad);
+  }
+  if (bad) return 1;
+  wsync<NW>();
+  if (tid == 0) {
+    const TV yaw = s.x0[2];  // src/mpc.py:64
+    const TV c = cos(yaw), sn = sin(yaw);
+    s.cy = c; s.sy = sn;
+    s.rzw0[0] = c * s.x0[6] - sn * s.x0[7];
+    s.rzw0[1] = sn * s.x0[6] + c * s.x0[7];
+    s.rzw0[2] = s.x0[8];
+  }
+  wsync<NW>();
+  for (int L = tid; L < NL; L += NT) {   // src/mpc.py:71-78, 98-107; compute_skew column a = r x e_a (src/utils.py:43-56)
+    const bool st = s.ct[L] != 0;
+    const TV rx = s.rr[3 * L], ry = s.rr[3 * L + 1], rz = s.rr[3 * L + 2];
+    const TV c = s.cy, sn = s.sy;
+    const TV Ib0 = (TV)cfg.Ib[0], Ib1 = (TV)cfg.Ib[1], Ib2 = (TV)cfg.Ib[2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      TV cx, cyv, cz;
+      if (a == 0) { cx = 0; cyv = rz; cz = -ry; }
+      else if (a == 1) { cx = -rz; cyv = 0; cz = rx; }
+      else { cx = ry; cyv = -rx; cz = 0; }
+      const TV bx = (c * cx + sn * cyv) * Ib0, by = (-sn * cx + c * cyv) * Ib1, bz = cz * Ib2;   // diag(Ib) Rz' col
+      const TV tx = c * bx - sn * by, ty = sn * bx + c * by;                                   // Ihat^-1 col
+      const TV m = st ? (TV)1 : (TV)0;
+      s.Bl[9 * L + 0 + a] = m * (c * tx - sn * ty);                                            // Rz Ihat^-1 col
+      s.Bl[9 * L + 3 + a] = m * (sn * tx + c * ty);
+      s.Bl[9 * L + 6 + a] = m * bz;
+    }
+    s.cm[L] = st ? s.inv_m : (TV)0;
+  }
+  // free response minus target, stages k = 1..N (closed forms: mpcqp_device.h struct_grad)
+  for (int e = tid; e < NQ; e += NT) {
+    const int j = e / 6, q = e - 6 * j, k = j + 1;
+    const TV d = s.delta, th = s.theta, g = s.x0[12], kd = (TV)k * d;
+    TV eP, eQ;
+    if (q < 3) {
+      eP = s.x0[q] + kd * s.rzw0[q] - (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, q);
+      const TV wx = (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, 6), wy = (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, 7),
+               wz = (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, 8);
+      const TV rd = q == 0 ? s.cy * wx - s.sy * wy : (q == 1 ? s.sy * wx + s.cy * wy : wz);
+      eQ = s.rzw0[q] - rd;
+    } else {
+      const int a = q - 3;
+      eP = s.x0[3 + a] + kd * s.x0[9 + a] - (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, 3 + a);
+      eQ = s.x0[9 + a] - (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, 9 + a);
+      if (a == 2) { eP += d * d * g * ((TV)(k * (k - 1)) * (TV)0.5 + th * (TV)k); eQ += kd * g; }
+    }
+    s.e0P[e] = eP; s.e0Q[e] = eQ;
+  }
+  wsync<NW>();
+  for (int e = tid; e < NQ; e += NT) {   // gam_jq = 2 sum_{k>j} [wP d^2 (k-1-j+th) eP_kq + wQ d eQ_kq]
+    const int j = e / 6, q = e - 6 * j;
+    const TV d = s.delta, th = s.theta;
+    TV aP = 0, aQ = 0;
+#pragma unroll
+    for (int k = 1; k <= N; ++k) {
+      const TV on = k > j ? (TV)1 : (TV)0;
+      aP = fma(on * ((TV)(k - 1 - j) + th), s.e0P[6 * (k - 1) + q], aP);
+      aQ = fma(on, s.e0Q[6 * (k - 1) + q], aQ);
+    }
+    s.gam[e] = (TV)2 * (s.wP[q] * d * d * aP + s.wQ[q] * d * aQ);
+  }
+  for (int i = tid; i < n; i += NT) { s.uv[i] = 0; s.ua[i] = 0.f; s.pu[i] = 0; }
+  for (int i = tid; i < NL * 5; i += NT) { s.za[i] = 0.f; s.ya[i] = 0.f; s.py[i] = 0; }
+  wsync<NW>();
+  TV g3[3];
+  w_grad<TV, N>(s, tabs.K, tid, g3);   // gradient at u = 0 = linear term
+  float q[1] = {0.f};
+  if (tid < NL) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { s.gl[3 * tid + a] = g3[a]; q[0] = fmaxf(q[0], fabsf((float)g3[a])); }
+  }
+  wmax<1, NW>(q, s.red, tid);
+  if (tid == 0) { s.gmax = q[0]; s.rho = (float)cfg.rho; s.iters = 0; s.psteps = 0; s.hard = 0; s.warm = 0; }
+  wsync<NW>();
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------- ADMM block
+// OSQP algorithm 1 on the rows  fz | fx - mu fz | fx + mu fz | fy - mu fz | fy + mu fz  of a leg-stage
+// (src/mpc.py:138-173), one lane per leg-stage, scaled duals yh = y / rho.
+template <typename TM>
+struct LegAdmm {
+  TM u[3], z[5], yh[5], g[3];
+  TM lo0, hi0, loA, hiB;     // fz box; friction rows: A rows in [loA, 0], B rows in [0, hiB]
+  TM mu;
+};
+
+template <typename TV, typename TM, int N>
+__device__ __forceinline__ float w_ratio(SmemW<TV, N>& s, const WrTabs& tabs, const LegAdmm<TM>& A, float rho, bool leg, int tid) {
+  constexpr int NL = WG<N>::NL, NW = WG<N>::NW;
+  if (tid < NL) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) s.uv[3 * tid + a] = (TV)A.u[a];
+  }
+  wsync<NW>();
+  TV hv[3];
+  w_grad<TV, N>(s, tabs.K, tid, hv);
+  float q[4] = {0.f, 0.f, 0.f, 0.f};
+  if (leg) {
+    const float mu = (float)A.mu, fx = (float)A.u[0], fy = (float)A.u[1], fz = (float)A.u[2], m = mu * fz;
+    const float gu[5] = {fz, fx - m, fx + m, fy - m, fy + m};
+    float y[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      y[i] = rho * (float)A.yh[i];
+      q[0] = fmaxf(q[0], fabsf(gu[i] - (float)A.z[i]));
+      q[2] = fmaxf(q[2], fmaxf(fabsf(gu[i]), fabsf((float)A.z[i])));
+    }
+    const float Gy[3] = {y[1] + y[2], y[3] + y[4], y[0] + mu * (-y[1] + y[2] - y[3] + y[4])};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      q[1] = fmaxf(q[1], fabsf((float)hv[a] + Gy[a]));
+      q[3] = fmaxf(q[3], fmaxf(fabsf((float)hv[a] - (float)A.g[a]), fabsf(Gy[a])));
+    }
+  }
+  wmax<4, NW>(q, s.red, tid);
+  const float sp = q[2], sd = fmaxf(q[3], s.gmax);
+  return sqrtf((q[0] / fmaxf(sp, 1e-12f)) / fmaxf(q[1] / fmaxf(sd, 1e-12f), 1e-30f));
+}
+
+#ifndef MPCQP_W_ADAPT_AT
+#define MPCQP_W_ADAPT_AT 25
+#endif
+
+// The leg's 6 x 3 wrench map [B_l ; contact / m I] and the inverse diagonal of D = 2 alpha + sigma + rho G'G.
+template <typename TV, typename TM, int N>
+__device__ __forceinline__ void w_admm_sys(const SmemW<TV, N>& s, const DevCfg& cfg, int L, float rho, LegSys<TM>& Ls) {
+  const bool stance = s.ct[L] != 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Ls.A[c][i] = (TM)s.Bl[9 * L + 3 * i + c];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) Ls.A[c][3 + a] = a == c ? (TM)s.cm[L] : (TM)0;
+  }
+  const TM r = (TM)rho, m = (TM)s.mu, a2 = (TM)(2.0 * cfg.alpha), sigma = (TM)cfg.sigma;
+  Ls.dinv[0] = Ls.dinv[1] = stance ? (TM)1 / (a2 + sigma + (TM)2 * r) : (TM)0;
+  Ls.dinv[2] = stance ? (TM)1 / (a2 + sigma + r * ((TM)1 + (TM)4 * m * m)) : (TM)0;
+}
+
+// One ADMM block from the state in s.ua / s.za / s.ya with penalty s.rho.  `adapt`: run the single early rho check (round 0
+// only); a QP that triggers it gets rho <- rho * ratio, a rebuilt matrix and a longer block.  Updates s.rho / s.iters /
+// s.hard / s.ratio and leaves the new iterate in s.ua/za/ya and s.pu/py.
+// Register phases that share nothing but LDS (see w_polish): E | tile + sweep | iterations.
+template <typename TV, typename TM, int N>
+__device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const WrTabs& tabs, const TM* __restrict__ kinvT, const int adapt,
+                                       const int kfirst, const int tid0) {
+  constexpr int NL = WG<N>::NL, NW = WG<N>::NW, G = WG<N>::G;
+  TM* const E = reinterpret_cast<TM*>(s.E);
+  TM* const piv = reinterpret_cast<TM*>(s.piv);
+  TM* const bv = reinterpret_cast<TM*>(s.bv);
+  TM* const cv = reinterpret_cast<TM*>(s.cv);
+  float rho = s.rho;
+  int K = kfirst > 0 ? min(kfirst, cfg.check_every) : cfg.check_every;
+  int it = 0, seg_end = (adapt && MPCQP_W_ADAPT_AT < K) ? MPCQP_W_ADAPT_AT : K;
+  int hard = 0;
+  float ratio = 0.f;
+  STAMP_INIT
+  for (;;) {
+    {   // ---- phase A: E = sum_legs A diag(dinv) A'
+      const int tid = opaque(tid0), L = min(tid, NL - 1);
+      LegSys<TM> Ls;
+      w_admm_sys<TV, TM, N>(s, cfg, L, rho, Ls);
+      w_build_E<TM, N>(Ls, E, tid);
+    }
+    STAMP(1);
+    WTile<TM> tile;
+    {   // ---- phase B: S = K^-1 + E, swept in place
+      const int tid = opaque(tid0), gr = tid / G, gc = tid % G;
+      w_tile_init<TM, N>(tile, kinvT, E, gr, gc, tid);
+      STAMP(2);
+      w_sweep<TM, N>(tile, piv, gr, gc);
+    }
+    STAMP(3);
+    {   // ---- phase C: iterations it .. seg_end from the state in LDS, state back to LDS
+      const int tid = opaque(tid0), L = min(tid, NL - 1), gr = tid / G, gc = tid % G;
+      const bool leg = tid < NL, stance = s.ct[L] != 0;
+      const TM sigma = (TM)cfg.sigma, relax = (TM)cfg.relax, om = (TM)1 - relax, BIG = (TM)1e30, r = (TM)rho;
+      if (tid >= WG<N>::NQ && tid < WG<N>::DP) bv[tid] = (TM)0;   // pad slots of the mat-vec input, in THIS phase's element type
+      LegSys<TM> Ls;                                               // (the fp64 polish overlays the same bytes)
+      w_admm_sys<TV, TM, N>(s, cfg, L, rho, Ls);
+      LegAdmm<TM> A;
+      A.mu = (TM)s.mu;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { A.u[a] = (TM)s.ua[3 * L + a]; A.g[a] = (TM)s.gl[3 * L + a]; }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { A.z[i] = (TM)s.za[5 * L + i]; A.yh[i] = (TM)(s.ya[5 * L + i] / rho); }
+      A.lo0 = stance ? (TM)s.fmin : (TM)0; A.hi0 = stance ? (TM)s.fmax : (TM)0;
+      A.loA = stance ? -BIG : (TM)0; A.hiB = stance ? BIG : (TM)0;
+      bool rebuild = false;
+      for (;;) {   // segments of iterations with the same matrix; the early rho check sits between the first two
+        const int n_it = __builtin_amdgcn_readfirstlane(seg_end - it);
+        for (int i = 0; i < n_it; ++i) {
+          // rhs = sigma u - g + rho G'(z - yh)
+          TM v[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) v[k] = A.z[k] - A.yh[k];
+          const TM w0 = v[1] + v[2], w1 = v[3] + v[4], w2 = fma(A.mu, (v[2] - v[1]) + (v[4] - v[3]), v[0]);
+          const TM rhs[3] = {fma(r, w0, fma(sigma, A.u[0], -A.g[0])), fma(r, w1, fma(sigma, A.u[1], -A.g[1])),
+                             fma(r, w2, fma(sigma, A.u[2], -A.g[2]))};
+          TM ut[3];
+          w_solve<TM, N>(tile, Ls, rhs, ut, bv, cv, tid, gr, gc);
+          const TM mz = A.mu * ut[2];
+          const TM gt[5] = {ut[2], ut[0] - mz, ut[0] + mz, ut[1] - mz, ut[1] + mz};
+#pragma unroll
+          for (int a = 0; a < 3; ++a) A.u[a] = fma(relax, ut[a], om * A.u[a]);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            const TM lo = k == 0 ? A.lo0 : ((k & 1) ? A.loA : (TM)0), hi = k == 0 ? A.hi0 : ((k & 1) ? (TM)0 : A.hiB);
+            const TM t = fma(relax, gt[k], om * A.z[k]) + A.yh[k];
+            const TM zn = fmin(fmax(t, lo), hi);
+            A.yh[k] = t - zn;
+            A.z[k] = zn;
+          }
+        }
+        it = seg_end;
+        STAMP(4);
+        ratio = w_ratio<TV, TM, N>(s, tabs, A, rho, leg, tid);   // OSQP's residual ratio at the end of the segment
+        STAMP(5);
+        if (it >= K) break;
+        if (ratio > ADAPT_THR) { rebuild = true; break; }        // uniform: slowly converging QP -> larger penalty, rebuilt matrix
+        seg_end = K;
+      }
+      if (leg) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s.ua[3 * L + a] = (float)A.u[a]; s.pu[3 * L + a] = (TV)A.u[a]; }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const float y = rho * (float)A.yh[k]; s.za[5 * L + k] = (float)A.z[k]; s.ya[5 * L + k] = y; s.py[5 * L + k] = (TV)y; }
+      }
+      wsync<NW>();
+      if (!rebuild) break;
+    }
+    rho = fminf(rho * ratio, ADAPT_RHO_MAX);   // ... and a longer block
+    hard = 1;
+    K = min(HARD_ITER_FACTOR * K, cfg.max_iter);
+    seg_end = K;
+  }
+  if (opaque(tid0) == 0) { s.rho = rho; s.iters += K; s.hard |= hard; s.ratio = ratio; }
+  wsync<NW>();
+}
+
+// ----------------------------------------------------------------------------------------------------- polish step
+// One primal-dual active-set step from (s.pu, s.py) (OSQP's `polish`, specialised to the 5 rows of a leg-stage): fz at a
+// bound and/or fx, fy tied to +-mu fz per leg; the equality-constrained QP is solved in the free variables through the
+// wrench-space system in TP precision; duals from stationarity; accepted only on a KKT check.  Returns 1 when accepted
+// (answer in s.uv), else 0 with (s.pu, s.py) replaced by the candidate.
+// The active set of a leg-stage as the polish uses it: zs / xs / ys in {-1, 0, +1} (fz at fmin / free / at fmax; fx, fy tied
+// to -mu fz / free / tied to +mu fz), packed as (zs + 1) | (xs + 1) << 2 | (ys + 1) << 4.
+struct ActSet {
+  int zs, xs, ys;
+  bool ez, ex, ey;
+  __device__ __forceinline__ ActSet(int code, bool stance) {
+    zs = (code & 3) - 1; xs = ((code >> 2) & 3) - 1; ys = ((code >> 4) & 3) - 1;
+    ez = stance && zs == 0; ex = stance && xs == 0; ey = stance && ys == 0;
+  }
+};
+
+// The leg's 6 x 3 reduced wrench map (tied tangential components ride on fz) and inverse diagonal 1 / (2 alpha Z'Z).
+template <typename TV, typename TP, int N>
+__device__ __forceinline__ void w_polish_sys(const SmemW<TV, N>& s, int L, const ActSet& a, LegSys<TP>& Ls) {
+  const TV muv = s.mu, txs = (TV)a.xs * muv, tys = (TV)a.ys * muv;
+  TV B[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) B[i] = s.Bl[9 * L + i];
+  const TV cm = s.cm[L];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Ls.A[0][i] = a.ex ? (TP)B[3 * i] : (TP)0;
+    Ls.A[1][i] = a.ey ? (TP)B[3 * i + 1] : (TP)0;
+    Ls.A[2][i] = a.ez ? (TP)(B[3 * i + 2] + txs * B[3 * i] + tys * B[3 * i + 1]) : (TP)0;
+  }
+  Ls.A[0][3] = a.ex ? (TP)cm : (TP)0; Ls.A[0][4] = 0; Ls.A[0][5] = 0;
+  Ls.A[1][3] = 0; Ls.A[1][4] = a.ey ? (TP)cm : (TP)0; Ls.A[1][5] = 0;
+  Ls.A[2][3] = a.ez ? (TP)(txs * cm) : (TP)0; Ls.A[2][4] = a.ez ? (TP)(tys * cm) : (TP)0; Ls.A[2][5] = a.ez ? (TP)cm : (TP)0;
+  const TV a2 = (TV)2 * s.alpha;
+  Ls.dinv[0] = a.ex ? (TP)((TV)1 / a2) : (TP)0;
+  Ls.dinv[1] = a.ey ? (TP)((TV)1 / a2) : (TP)0;
+  Ls.dinv[2] = a.ez ? (TP)((TV)1 / (a2 * ((TV)1 + muv * muv * (TV)((a.xs != 0) + (a.ys != 0))))) : (TP)0;
+}
+
+// One primal-dual active-set step from (s.pu, s.py) (OSQP's `polish`, specialised to the 5 rows of a leg-stage): fz at a
+// bound and/or fx, fy tied to +-mu fz per leg; the equality-constrained QP is solved in the free variables through the
+// wrench-space system in TP precision; duals from stationarity; accepted only on a KKT check.  Returns 1 when accepted
+// (answer in s.uv), else 0 with (s.pu, s.py) replaced by the candidate.
+// Three register phases (rule + E | tile + sweep | solve + KKT) that share nothing but LDS: the fp64 tile is half of the
+// register file, so whatever else stays alive across the sweep is spilled to scratch inside the pivot loop.  Each phase
+// re-derives its lane roles from an opaque copy of the lane index and re-reads its data from LDS.
+template <typename TV, typename TP, int N>
+__device__ __forceinline__ int w_polish(SmemW<TV, N>& s, const WrTabs& tabs, const TP* __restrict__ kinvT, const int tid0) {
+  constexpr int NL = WG<N>::NL, NW = WG<N>::NW, G = WG<N>::G;
+  TP* const E = reinterpret_cast<TP*>(s.E);
+  TP* const piv = reinterpret_cast<TP*>(s.piv);
+  TP* const bv = reinterpret_cast<TP*>(s.bv);
+  TP* const cv = reinterpret_cast<TP*>(s.cv);
+  STAMP_INIT
+  {   // ---- phase A: active-set rule on (pu, py): rows 0 fz | 1 fx - mu fz <= 0 | 2 fx + mu fz >= 0 | 3,4 same for fy
+    const int tid = opaque(tid0), L = min(tid, NL - 1);
+    const bool stance = s.ct[L] != 0;
+    const TV muv = s.mu, fminv = s.fmin, fmaxv = s.fmax;
+    int zs = 0, xs = 0, ys = 0;
+    if (stance) {
+      const TV u0 = s.pu[3 * L], u1 = s.pu[3 * L + 1], u2 = s.pu[3 * L + 2];
+      const TV y0 = s.py[5 * L], y1 = s.py[5 * L + 1], y2 = s.py[5 * L + 2], y3 = s.py[5 * L + 3], y4 = s.py[5 * L + 4];
+      const TV g1 = u0 - muv * u2, g2 = u0 + muv * u2, g3_ = u1 - muv * u2, g4 = u1 + muv * u2;
+      if (y0 + (u2 - fmaxv) > 0) zs = 1;
+      else if (y0 + (u2 - fminv) < 0) zs = -1;
+      const bool hx = y1 + g1 > 0, lx = y2 + g2 < 0;
+      if (hx && lx) xs = (g1 > -g2) ? 1 : -1; else if (hx) xs = 1; else if (lx) xs = -1;
+      const bool hy = y3 + g3_ > 0, ly = y4 + g4 < 0;
+      if (hy && ly) ys = (g3_ > -g4) ? 1 : -1; else if (hy) ys = 1; else if (ly) ys = -1;
+    }
+    const int code = (zs + 1) | ((xs + 1) << 2) | ((ys + 1) << 4);
+    if (tid < NL) s.aset[L] = (uint8_t)code;
+    const ActSet as(code, stance);
+    LegSys<TP> Ls;
+    w_polish_sys<TV, TP, N>(s, L, as, Ls);
+    wsync<NW>();   // everyone has read pu / py of this round
+    w_build_E<TP, N>(Ls, E, tid);
+  }
+  STAMP(9);
+  WTile<TP> tile;
+  {   // ---- phase B: S = K^-1 + E, swept in place
+    const int tid = opaque(tid0), gr = tid / G, gc = tid % G;
+    w_tile_init<TP, N>(tile, kinvT, E, gr, gc, tid);
+    STAMP(10);
+    w_sweep<TP, N>(tile, piv, gr, gc);
+  }
+  STAMP(11);
+  // ---- phase C: solve in the free variables from the projection of pu, duals, KKT
+  const int tid = opaque(tid0), L = min(tid, NL - 1), gr = tid / G, gc = tid % G;
+  const bool leg = tid < NL, stance = s.ct[L] != 0;
+  if (tid >= WG<N>::NQ && tid < WG<N>::DP) bv[tid] = (TP)0;   // pad slots of the mat-vec input, in this phase's element type
+  const ActSet as(s.aset[L], stance);
+  const int zs = as.zs, xs = as.xs, ys = as.ys;
+  const bool ez = as.ez, ex = as.ex, ey = as.ey;
+  const TV muv = s.mu, fminv = s.fmin, fmaxv = s.fmax;
+  const TV txs = (TV)xs * muv, tys = (TV)ys * muv;
+  const float gmaxf = s.gmax;
+  const float tol_stat = (sizeof(TV) == 8) ? (1e-6f + 1e-9f * gmaxf) : (3e-7f * fmaxf(gmaxf, 1.f));
+  const float acc_stat = (sizeof(TV) == 8) ? (1e-5f + 1e-8f * gmaxf) : (1e-5f * fmaxf(gmaxf, 1.f));
+  const float ftol = (sizeof(TV) == 8) ? 1e-7f : 2e-5f;
+  const float dtol = (sizeof(TV) == 8) ? (1e-5f + 1e-9f * gmaxf) : (2e-5f * fmaxf(1.f, gmaxf));
+  TV up3[3] = {0, 0, 0};
+  if (stance && zs != 0) {
+    const TV F = zs > 0 ? fmaxv : fminv;
+    up3[2] = F; up3[0] = txs * F; up3[1] = tys * F;
+  }
+  TV v3[3] = {ex ? s.pu[3 * L] : (TV)0, ey ? s.pu[3 * L + 1] : (TV)0, ez ? s.pu[3 * L + 2] : (TV)0};
+  TV uc[3], gr3[3] = {0, 0, 0};
+  auto expand = [&]() {
+    uc[0] = up3[0]; uc[1] = up3[1]; uc[2] = up3[2];
+    if (ez) { uc[2] = v3[2]; uc[0] = txs * v3[2]; uc[1] = tys * v3[2]; }
+    if (ex) uc[0] = v3[0];
+    if (ey) uc[1] = v3[1];
+  };
+  float stat = INFINITY, prev = INFINITY;
+  for (int rf = 0;; ++rf) {
+    expand();
+    if (leg) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s.uv[3 * L + c] = uc[c];
+    }
+    wsync<NW>();
+    w_grad<TV, N>(s, tabs.K, tid, gr3);
+    TV rg[3] = {ex ? gr3[0] : (TV)0, ey ? gr3[1] : (TV)0, ez ? gr3[2] + txs * gr3[0] + tys * gr3[1] : (TV)0};
+    float q[1] = {leg ? fmaxf(fmaxf(fabsf((float)rg[0]), fabsf((float)rg[1])), fabsf((float)rg[2])) : 0.f};
+    if (!isfinite(q[0])) q[0] = INFINITY;
+    wmax<1, NW>(q, s.red, tid);
+    prev = stat; stat = q[0];
+    if (stat <= tol_stat || rf >= 4 || (rf > 0 && !(stat < 0.5f * prev))) break;   // converged / stagnated (uniform)
+    const TP rhs[3] = {(TP)(-rg[0]), (TP)(-rg[1]), (TP)(-rg[2])};
+    TP dx[3];
+    {
+      LegSys<TP> Ls;
+      w_polish_sys<TV, TP, N>(s, L, as, Ls);
+      w_solve<TP, N>(tile, Ls, rhs, dx, bv, cv, tid, gr, gc);
+    }
+    v3[0] += ex ? (TV)dx[0] : (TV)0; v3[1] += ey ? (TV)dx[1] : (TV)0; v3[2] += ez ? (TV)dx[2] : (TV)0;
+  }
+  // duals from stationarity grad_leg + G_A' y_A = 0, then primal feasibility + dual sign
+  TV yn[5] = {0, 0, 0, 0, 0};
+  float viol[3] = {0.f, 0.f, 0.f};
+  if (leg && stance) {
+    TV zacc = gr3[2];
+    if (xs > 0) { yn[1] = -gr3[0]; zacc += muv * (-yn[1]); }
+    else if (xs < 0) { yn[2] = -gr3[0]; zacc += muv * yn[2]; }
+    if (ys > 0) { yn[3] = -gr3[1]; zacc += muv * (-yn[3]); }
+    else if (ys < 0) { yn[4] = -gr3[1]; zacc += muv * yn[4]; }
+    if (zs != 0) yn[0] = -zacc;
+    const TV g0 = uc[2], g1 = uc[0] - muv * uc[2], g2 = uc[0] + muv * uc[2], g3_ = uc[1] - muv * uc[2], g4 = uc[1] + muv * uc[2];
+    TV pv = fmax(fminv - g0, g0 - fmaxv);
+    pv = fmax(pv, fmax(g1, -g2));
+    pv = fmax(pv, fmax(g3_, -g4));
+    TV dv = fmax(fmax(-yn[1], yn[2]), fmax(-yn[3], yn[4]));
+    if (zs > 0) dv = fmax(dv, -yn[0]);
+    if (zs < 0) dv = fmax(dv, yn[0]);
+    viol[0] = (float)fmax(pv, (TV)0);
+    viol[1] = (float)fmax(dv, (TV)0);
+    viol[2] = fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2]));
+    if (!(isfinite(viol[0]) && isfinite(viol[1]))) viol[0] = viol[1] = INFINITY;
+  }
+  wmax<3, NW>(viol, s.red, tid);
+  // a stationarity / dual-sign slack e moves the forces by ~e / (2 alpha): scale the acceptance with the curvature so that
+  // `solved` implies the 1e-4 band for any alpha
+  const float a2f = (sizeof(TV) == 8) ? 2.f * (float)s.alpha : 1e30f, uscale = fmaxf(1.f, viol[2]);
+  const bool ok = viol[0] <= ftol * uscale && viol[1] <= fminf(dtol, a2f * 1e-5f * uscale) && stat <= fminf(acc_stat, a2f * 2e-5f * uscale);
+  STAMP(6);
+  if (leg) {   // publish the candidate as the next polish iterate / the answer (s.uv already holds it)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s.pu[3 * L + c] = uc[c];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s.py[5 * L + i] = yn[i];
+  }
+  if (tid == 0) { s.kkt[0] = stat; s.kkt[1] = viol[0]; s.kkt[2] = viol[1]; s.psteps += 1; }
+  wsync<NW>();
+  STAMP(7);
+  return ok ? 1 : 0;
+}
+
+// ----------------------------------------------------------------------------------------------------- output
+template <typename TV, typename TIO, int N>
+__device__ __forceinline__ void w_output(SmemW<TV, N>& s, const WrTabs& tabs, TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __restrict__ statusg,
+                                         int* __restrict__ itersg, float* __restrict__ resg, float* __restrict__ y_state, const size_t b,
+                                         const int ok, const int tid) {
+  constexpr int NT = WG<N>::NT, NL = WG<N>::NL, n = WG<N>::n, NW = WG<N>::NW;
+  STAMP_INIT
+  for (int L = tid; L < NL; L += NT) {
+    const bool stance = s.ct[L] != 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      TV v = ok ? s.uv[3 * L + c] : (TV)s.ua[3 * L + c];   // iteration cap: hand back the last ADMM iterate
+      if (!stance) v = 0;
+      s.uv[3 * L + c] = v;
+    }
+  }
+  wsync<NW>();
+  for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)s.uv[i];   // src/mpc.py:267-268
+  if (y_state) {
+    for (int i = tid; i < NL * 5; i += NT) y_state[b * (NL * 5) + i] = ok ? (float)s.py[i] : s.ya[i];
+  }
+  if (Xg) {                                                          // src/mpc.py:265-266: roll the model forward (closed forms)
+    TV g3[3];
+    w_grad<TV, N>(s, tabs.K, tid, g3);                               // leaves the stage wrenches in s.ww
+    const TV d = s.delta, th = s.theta, g = s.x0[12];
+    for (int i = tid; i < (N + 1) * 13; i += NT) {
+      const int k = i / 13, c = i % 13;
+      TV v;
+      if (c == 12 || k == 0) v = s.x0[c];
+      else if (c < 6) {
+        const int q = c;
+        TV acc = 0;
+        for (int j = 0; j < k; ++j) acc = fma((TV)(k - 1 - j) + th, s.ww[6 * j + q], acc);
+        v = c < 3 ? s.x0[c] + (TV)k * d * s.rzw0[c] + d * d * acc : s.x0[c] + (TV)k * d * s.x0[6 + c] + d * d * acc;
+        if (c == 5) v += d * d * g * ((TV)(k * (k - 1)) * (TV)0.5 + th * (TV)k);
+      } else if (c < 9) {
+        TV ax = 0, ay = 0, az = 0;
+        for (int j = 0; j < k; ++j) { ax += s.ww[6 * j]; ay += s.ww[6 * j + 1]; az += s.ww[6 * j + 2]; }
+        const TV rot = c == 6 ? s.cy * ax + s.sy * ay : (c == 7 ? -s.sy * ax + s.cy * ay : az);   // omega = Rz'(Rz omega)
+        v = s.x0[c] + d * rot;
+      } else {
+        TV acc = 0;
+        for (int j = 0; j < k; ++j) acc += s.ww[6 * j + (c - 6)];
+        v = s.x0[c] + d * acc;
+        if (c == 11) v += (TV)k * d * g;
+      }
+      Xg[b * (size_t)(N + 1) * 13 + i] = (TIO)v;
+    }
+  }
+  if (tid == 0) {
+    statusg[b] = ok ? MPCQP_STATUS_SOLVED_POLISHED : MPCQP_STATUS_MAX_ITER;
+    itersg[b] = s.iters + 1000 * s.psteps;
+    if (resg) { resg[2 * b] = s.kkt[1]; resg[2 * b + 1] = fmaxf(s.kkt[2], s.kkt[0]); }
+  }
+  STAMP(8);
+}
+
+// ----------------------------------------------------------------------------------------------------- the kernel
+// Plain form: blockIdx = QP.  Queued form (ob.list != null): resident workgroups pull QPs dearest-expected-first from
+// the queue the pre-pass of mpcqp_fast.h fills; every wave leaves when the queue index passes Btot.
+template <typename TV, typename TM, typename TP, typename TIO, int N, bool GAIT>
+__global__ void __launch_bounds__(WG<N>::NT, 2)
+mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const FastIn<TIO> in, TIO* ug, TIO* __restrict__ Xg,
+                   int* __restrict__ statusg, int* __restrict__ itersg, float* __restrict__ resg, const OrderBuf ob, const int Btot) {
+  constexpr int NT = WG<N>::NT, n = WG<N>::n, G = WG<N>::G, NW = WG<N>::NW;
+  __shared__ SmemW<TV, N> s;
+  __shared__ int s_next;
+  const DevCfg& cfg = *cfgp;
+  const TM* kinvM; const TP* kinvP;
+  if constexpr (sizeof(TM) == 4) kinvM = tabs.kinv32; else kinvM = tabs.kinv64;
+  if constexpr (sizeof(TP) == 4) kinvP = tabs.kinv32; else kinvP = tabs.kinv64;
+  for (int guard = 0; guard <= Btot; ++guard) {
+    // The lane index is made opaque once per QP: everything derived from it (addresses into the constant tables, role
+    // masks, loop coefficients) is invariant across the QPs of a resident wave, and LLVM would hoist all of it out of
+    // this loop -- several hundred registers' worth, spilled for the whole kernel.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int gr = tid / G, gc = tid % G;
+    size_t b = blockIdx.x;
+    if (ob.list) {
+      if (tid == 0) s_next = atomicAdd(ob.head, 1);
+      __syncthreads();
+      int i = s_next;
+      __syncthreads();
+      if (i >= Btot) break;                  // uniform
+      for (int k = ORDER_BUCKETS - 1; k >= 0; --k) {
+        const int c = ob.cnt[k];
+        if (i < c) { b = (size_t)ob.list[(size_t)k * ob.cap + i]; break; }
+        i -= c;
+      }
+    }
+#ifdef MPCQP_STAMPS
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    STAMP_INIT
+    if (w_setup<TV, TIO, N, GAIT>(s, cfg, tabs, in, b, tid, guard == 0)) {   // non-finite input -> zero outputs, status -1
+      for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
+      if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (size_t)(N + 1) * 13 + i] = (TIO)0;
+      if (tid == 0) {
+        statusg[b] = MPCQP_STATUS_NONFINITE;
+        itersg[b] = 0;
+        if (resg) { resg[2 * b] = 0.f; resg[2 * b + 1] = 0.f; }
+      }
+      if (!ob.list) break;
+      continue;
+    }
+    STAMP(0);
+    const int max_iter = cfg.max_iter, polish_max = cfg.polish_max;
+    int ok = 0;
+    for (int round = 0; !ok; ++round) {
+      w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, 0, tid);
+      const int budget = (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
+      for (int ps = 0; ps < budget && !ok; ++ps) ok = w_polish<TV, TP, N>(s, tabs, kinvP, tid);
+      if (ok || s.iters >= max_iter) break;
+      const float ratio = s.ratio;   // not solved: OSQP's rho adaptation from the residuals of the last ADMM iterate, then another block
+      if (tid == 0 && isfinite(ratio) && (ratio > 2.f || ratio < 0.5f)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
+      wsync<NW>();
+    }
+    w_output<TV, TIO, N>(s, tabs, ug, Xg, statusg, itersg, resg, in.y_state, b, ok, tid);
+#ifdef MPCQP_STAMPS
+    if (tid == 0 && b < 65536) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_timeline[3 * b] = tl_t0; g_timeline[3 * b + 1] = __builtin_amdgcn_s_memtime();
+      g_timeline[3 * b + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+    if (!ob.list) break;
+  }
+}
+
+}  // namespace

@@ -74,6 +74,7 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
 
 int mpcqp_destroy(mpcqp_handle h) { free(h); return MPCQP_OK; }
 const char* mpcqp_last_error(mpcqp_handle h) { return h ? h->err : "null handle"; }
+int mpcqp_reserve(mpcqp_handle h, int64_t B) { (void)B; return h ? MPCQP_OK : MPCQP_EINVAL; }   /* host memory: nothing to pre-size */
 int mpcqp_last_kernel_ms(mpcqp_handle h, float* ms) { if (!h || !ms) return MPCQP_EINVAL; *ms = h->last_ms; return MPCQP_OK; }
 
 /* ---------------------------------------------------------------- model, literal to src/mpc.py ------- */
