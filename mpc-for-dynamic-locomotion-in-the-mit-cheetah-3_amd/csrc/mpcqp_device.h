@@ -14,11 +14,15 @@
 
 namespace {
 
+#if defined(MPCQP_STAMPS) || defined(MPCQP_WDBG)
+__device__ double g_wdbg[2048];   // diagnostic builds: wrench-space engine, setup products of QP 0
+#endif
 // Diagnostic build only (-DMPCQP_STAMPS -> libmpcqp_stamps.so): per-phase shader-cycle sums over all workgroups.
 // Never compiled into libmpcqp.so; the values leave through their own buffer and feed no output.
 #ifdef MPCQP_STAMPS
 __device__ unsigned long long g_stamps[32];
-__device__ unsigned long long g_timeline[65536 * 3];   // per QP: start tick, end tick, (xcc << 32 | hw_id): who ran it and when
+__device__ unsigned long long g_timeline[65536 * 3];
+   // per QP: start tick, end tick, (xcc << 32 | hw_id): who ran it and when
 #define STAMP_INIT unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_t1;
 #define STAMP(i)                                                       \
   do {                                                                 \

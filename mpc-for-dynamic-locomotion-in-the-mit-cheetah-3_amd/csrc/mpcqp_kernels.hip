@@ -41,6 +41,47 @@ mpcqp_torque_kernel(const TIO* __restrict__ u, const TIO* __restrict__ jac, TIO*
   for (int q = 0; q < 3; ++q) tau[i * 3 + q] = J[0 * 3 + q] * fx + J[1 * 3 + q] * fy + J[2 * 3 + q] * fz;
 }
 
+// Gait entry point (mpcqp_solve_batch_gait): what MPC.solve computes on the host every tick (src/mpc.py:178-254) from the planner
+// queries (src/footstep_planner.py:226-246), for B robots at once, into the engine's own tuple workspace:
+//   x_des[k]   = [roll0, pitch0, yaw_start + k d w, com_start + k d v, 0, 0, w, v, g]             (src/mpc.py:202-214)
+//   contact[k] = feet_id[step(k)] during that step's first ss ticks, else all stance          (footstep_planner.py:239-246)
+//   r[0]       = measured foot - measured com;  r[k>=1] = planned foothold of step(k) - x_des com(k)   (src/mpc.py:218-239)
+// with step(k) = 0 while t_in_step + k < ss + ds, else 1.  Element-wise and HBM-bound (about 100 B in, 1.1 KB out per QP, which
+// the solve kernel then reads from L2): one thread per output element, consecutive threads write consecutive addresses.
+template <typename TIO>
+__global__ void __launch_bounds__(256)
+mpcqp_gait_expand_kernel(const FastIn<TIO> in, const double d, const int N, const int64_t B, TIO* __restrict__ r, uint8_t* __restrict__ contact,
+                         TIO* __restrict__ xdes) {
+  const int nx = (N + 1) * 13, nr = N * 12, per = nx + nr;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * per) return;
+  const int64_t b = t / per;
+  const int e = (int)(t - b * per);
+  const TIO* ref = in.ref + b * 10;
+  if (e < nx) {
+    const int k = e / 13, c = e % 13;
+    double v;
+    if (c < 2) v = (double)ref[c];
+    else if (c == 2) v = (double)ref[2] + (double)k * d * (double)ref[9];
+    else if (c < 6) v = (double)ref[c] + (double)k * d * (double)ref[6 + (c - 3)];
+    else if (c < 8) v = 0.0;
+    else if (c == 8) v = (double)ref[9];
+    else if (c < 12) v = (double)ref[6 + (c - 9)];
+    else v = (double)in.x0[b * 13 + 12];
+    xdes[b * nx + e] = (TIO)v;
+  } else {
+    const int i = e - nx, k = i / 12, l = (i % 12) / 3, a = i % 3;
+    const int tis = in.gait[b * 4 + 0], ss = in.gait[b * 4 + 1], ds = in.gait[b * 4 + 2];
+    int tau = tis + k, st = 0;
+    if (tau >= ss + ds) { tau -= ss + ds; st = 1; }
+    double v;
+    if (k == 0) v = (double)in.feet0[b * 12 + l * 3 + a] - (double)in.x0[b * 13 + 3 + a];
+    else v = (double)in.footholds[b * 24 + st * 12 + l * 3 + a] - ((double)ref[3 + a] + (double)k * d * (double)ref[6 + a]);
+    r[b * nr + i] = (TIO)v;
+    if (a == 0) contact[b * (N * 4) + k * 4 + l] = (tau < ss) ? (in.feet_id[b * 8 + st * 4 + l] ? 1 : 0) : 1;
+  }
+}
+
 }  // namespace
 
 // ======================================================================================================
@@ -58,10 +99,13 @@ struct mpcqp_engine {
   double* wr_K = nullptr;     // wrench-space engine (mpcqp_wrench.h): K_q [6][N][N], K^-1 in tile layout (fp32 / fp64)
   float* wr_kinv32 = nullptr;
   double* wr_kinv64 = nullptr;
+  void* gait_mem = nullptr;   // gait entry point: the expanded operator tuple [r | xdes | contact] of the current batch
+  int64_t gait_cap = 0;
   bool wrench_ok = false;     // the configuration admits the wrench-space form (isotropic omega weight, positive velocity weights)
   float* dual_mem = nullptr;  // warm-started engines: multipliers of the previous solve per batch slot [dual_cap][200]
   int64_t dual_cap = 0;
   bool timed = false;
+  bool ev0_set = false;       // the gait entry point has already recorded the start event (in front of its expansion kernel)
   char err[512];
 };
 
@@ -111,20 +155,22 @@ hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* 
   return hipGetLastError();
 }
 
-// Wrench-space engine (mpcqp_wrench.h): one QP per wave (horizon 10), 2 waves per SIMD = 8 resident workgroups per CU.
-template <typename TIO, bool GAIT>
+// Wrench-space engine (mpcqp_wrench.h).  Horizon 10: one QP per wave, 2 waves per SIMD = 8 resident workgroups per CU, queued
+// launch form for batches that oversubscribe them.  Horizon 20: one QP per 4-wave workgroup, plain launch form.
+template <typename TIO, bool GAIT, int N>
 hipError_t launch_wrench(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
                          float* res, hipStream_t s) {
-  constexpr int N = 10;
   dim3 grid((unsigned)B);
   OrderBuf ob = {nullptr, nullptr, 0, nullptr};
-  const int64_t slots = 4 * (int64_t)e->slots;   // e->slots = 2 per CU
-  if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && slots > 0 && B > slots && e->order_cap >= B) {
-    ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 32; ob.cap = e->order_cap;
-    hipError_t he = hipMemsetAsync(ob.cnt, 0, 32 * sizeof(int), s);
-    if (he != hipSuccess) return he;
-    hipLaunchKernelGGL((mpcqp_order_kernel<TIO, GAIT>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
-    grid = dim3((unsigned)slots);
+  if constexpr (N == 10) {   // (the dispatch-order pre-pass of mpcqp_fast.h reads horizon-10 tuples)
+    const int64_t slots = 4 * (int64_t)e->slots;   // e->slots = 2 per CU
+    if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && slots > 0 && B > slots && e->order_cap >= B) {
+      ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 32; ob.cap = e->order_cap;
+      hipError_t he = hipMemsetAsync(ob.cnt, 0, 32 * sizeof(int), s);
+      if (he != hipSuccess) return he;
+      hipLaunchKernelGGL((mpcqp_order_kernel<TIO, GAIT>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
+      grid = dim3((unsigned)slots);
+    }
   }
   const WrTabs tabs = {e->wr_K, e->wr_kinv32, e->wr_kinv64};
   if (e->cfg.precision == MPCQP_PREC_MIXED)
@@ -134,6 +180,14 @@ hipError_t launch_wrench(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void
     hipLaunchKernelGGL((mpcqp_wrench_solve<double, double, double, TIO, N, GAIT>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
                        (TIO*)X, st, it, res, ob, (int)B);
   return hipGetLastError();
+}
+
+template <typename TIO, bool GAIT>
+hipError_t launch_wrench_n(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
+                           float* res, hipStream_t s) {
+  static_assert(!GAIT, "the gait entry point expands its descriptors into a tuple first");
+  if (e->cfg.N == 10) return launch_wrench<TIO, false, 10>(e, B, in, u, X, st, it, res, s);
+  return launch_wrench<TIO, false, 20>(e, B, in, u, X, st, it, res, s);
 }
 
 // Workspace that depends on the batch size: the dispatch-order buffer of the queued launch forms and, for warm-started
@@ -162,6 +216,17 @@ int reserve_workspace(mpcqp_engine* e, int64_t B) {
   return MPCQP_OK;
 }
 
+// Tuple workspace of the gait entry point, grown like the rest of the batch-dependent workspace.
+int reserve_gait(mpcqp_engine* e, int64_t B) {
+  if (B <= e->gait_cap) return MPCQP_OK;
+  const size_t el = e->cfg.dtype == MPCQP_DTYPE_F64 ? 8 : 4, N = (size_t)e->cfg.N;
+  void* mem = nullptr;
+  if (hipMalloc(&mem, (size_t)B * ((N * 12 + (N + 1) * 13) * el + N * 4)) != hipSuccess) { (void)hipGetLastError(); return MPCQP_ENOMEM; }
+  if (e->gait_mem) { (void)hipDeviceSynchronize(); (void)hipFree(e->gait_mem); }
+  e->gait_mem = mem; e->gait_cap = B;
+  return MPCQP_OK;
+}
+
 // Every entry point runs on the handle's device whatever the caller's current device is, and puts that one back.
 struct DeviceGuard {
   int prev = -1; bool switched = false; hipError_t err = hipSuccess;
@@ -173,8 +238,8 @@ struct DeviceGuard {
 };
 
 bool wrench_path_applies(const mpcqp_engine* h) {
-  return h->wrench_ok && h->cfg.N == 10 && h->cfg.precision != MPCQP_PREC_F32 && (h->cfg.flags & MPCQP_FLAG_POLISH) &&
-         !(h->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL | MPCQP_FLAG_WARM_START)) && h->cfg.alpha > 0.0;
+  return h->wrench_ok && h->cfg.precision != MPCQP_PREC_F32 && (h->cfg.flags & MPCQP_FLAG_POLISH) &&
+         !(h->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL)) && h->cfg.alpha > 0.0;
 }
 
 bool fast_path_applies(const mpcqp_engine* h) {
@@ -268,6 +333,7 @@ static void free_engine(mpcqp_engine* h) {
   if (h->dcfg) (void)hipFree(h->dcfg);
   if (h->order_mem) (void)hipFree(h->order_mem);
   if (h->dual_mem) (void)hipFree(h->dual_mem);
+  if (h->gait_mem) (void)hipFree(h->gait_mem);
   if (h->wr_K) (void)hipFree(h->wr_K);
   if (h->wr_kinv32) (void)hipFree(h->wr_kinv32);
   if (h->wr_kinv64) (void)hipFree(h->wr_kinv64);
@@ -315,7 +381,6 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   auto reject = [&](int code) { free_engine(e); return code; };
   if (!(N == 10 || N == 20)) return reject(MPCQP_EINVAL);
   if (cfg->precision < MPCQP_PREC_F32 || cfg->precision > MPCQP_PREC_F64) return reject(MPCQP_EINVAL);
-  if (cfg->precision == MPCQP_PREC_F64 && N != 10) return reject(MPCQP_EINVAL);
   if (cfg->dtype != MPCQP_DTYPE_F32 && cfg->dtype != MPCQP_DTYPE_F64) return reject(MPCQP_EINVAL);
   if (cfg->disc != MPCQP_DISC_EULER && cfg->disc != MPCQP_DISC_ZOH) return reject(MPCQP_EINVAL);
   if (!(cfg->delta > 0) || !(cfg->m > 0) || !(cfg->rho > 0) || !(cfg->sigma >= 0) || !(cfg->relax > 0 && cfg->relax < 2) ||
@@ -359,7 +424,9 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
     }
   hipError_t he = hipMalloc((void**)&e->ctab, sizeof(double) * 2 * N * N);
   if (he == hipSuccess) he = hipMemcpy(e->ctab, tab, sizeof(double) * 2 * N * N, hipMemcpyHostToDevice);
-  if (he == hipSuccess && N == 10) e->wrench_ok = build_wrench_tables<10>(e, tab);
+  if (he == hipSuccess) e->wrench_ok = N == 10 ? build_wrench_tables<10>(e, tab) : build_wrench_tables<20>(e, tab);
+  // (all-fp64 arithmetic at horizon 20 exists only in the wrench-space engine)
+  if (he == hipSuccess && cfg->precision == MPCQP_PREC_F64 && N != 10 && !wrench_path_applies(e)) { delete[] tab; return reject(MPCQP_EINVAL); }
   delete[] tab;
   if (he == hipSuccess) he = hipMalloc((void**)&e->dcfg, sizeof(DevCfg));
   if (he == hipSuccess) he = hipMemcpy(e->dcfg, &e->dev, sizeof(DevCfg), hipMemcpyHostToDevice);
@@ -401,20 +468,21 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
   const bool wrench = wrench_path_applies(h), fast = !wrench && fast_path_applies(h);
   const bool warm = (h->cfg.flags & MPCQP_FLAG_WARM_START) != 0;   // u_out is read as the initial guess first
   if ((wrench || fast) && reserve_workspace(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_solve_batch: workspace allocation failed");
-  float* ys = (warm && fast && B > 0) ? h->dual_mem : nullptr;
+  float* ys = (warm && (fast || wrench) && B > 0) ? h->dual_mem : nullptr;
   const int shift = (h->cfg.flags & MPCQP_FLAG_WARM_SHIFT) ? 1 : 0;
-  he = hipEventRecord(h->ev0, st);
+  if (!h->ev0_set) he = hipEventRecord(h->ev0, st);
+  h->ev0_set = false;
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
   if (B > 0 && (wrench || fast)) {
     if (h->cfg.dtype == MPCQP_DTYPE_F64) {
       const FastIn<double> in = {(const double*)x0, (const double*)r, contact, (const double*)xdes, (const double*)mu,
                                  nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const double*)u_out : nullptr, ys, shift};
-      he = wrench ? launch_wrench<double, false>(h, B, in, u_out, X_out, status, iters, res, st)
+      he = wrench ? launch_wrench_n<double, false>(h, B, in, u_out, X_out, status, iters, res, st)
                   : launch_fast<double, false>(h, B, in, u_out, X_out, status, iters, res, st);
     } else {
       const FastIn<float> in = {(const float*)x0, (const float*)r, contact, (const float*)xdes, (const float*)mu,
                                 nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const float*)u_out : nullptr, ys, shift};
-      he = wrench ? launch_wrench<float, false>(h, B, in, u_out, X_out, status, iters, res, st)
+      he = wrench ? launch_wrench_n<float, false>(h, B, in, u_out, X_out, status, iters, res, st)
                   : launch_fast<float, false>(h, B, in, u_out, X_out, status, iters, res, st);
     }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
@@ -441,38 +509,35 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
   if (B < 0 || B > 0x7fffffff) return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: batch size out of range");
   if (B > 0 && (!x0 || !ref || !feet0 || !footholds || !gait || !feet_id || !mu || !u_out || !status || !iters))
     return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: null buffer");
-  const bool wrench = wrench_path_applies(h);
-  if (!wrench && !fast_path_applies(h))
-    return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: needs N = 10, polish, alpha > 0 (and MIXED or F32 precision on the tile kernel)");
+  if (h->cfg.N != 10 || !(wrench_path_applies(h) || fast_path_applies(h)))
+    return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: needs N = 10, polish, alpha > 0");
+  if (B == 0) return mpcqp_solve_batch(h, 0, x0, nullptr, nullptr, nullptr, mu, u_out, X_out, status, iters, res, stream);
   DeviceGuard guard(h->cfg.device);
   if (guard.err != hipSuccess) return fail(h, MPCQP_EHIP, "hipSetDevice", guard.err);
+  if (reserve_gait(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_solve_batch_gait: workspace allocation failed");
+  // expand the descriptors on the device into the engine's tuple workspace, then the normal solve on that tuple
+  const size_t el = h->cfg.dtype == MPCQP_DTYPE_F64 ? 8 : 4, N = (size_t)h->cfg.N;
+  char* base = (char*)h->gait_mem;
+  void* r = base;
+  void* xdes = base + (size_t)B * N * 12 * el;
+  uint8_t* contact = (uint8_t*)(base + (size_t)B * (N * 12 + (N + 1) * 13) * el);
+  const int64_t total = B * (int64_t)(N * 12 + (N + 1) * 13);
+  const dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t st = (hipStream_t)stream;
-  const bool warm = (h->cfg.flags & MPCQP_FLAG_WARM_START) != 0;
-  if (reserve_workspace(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_solve_batch_gait: workspace allocation failed");
-  float* ys = (warm && B > 0) ? h->dual_mem : nullptr;
-  const int shift = (h->cfg.flags & MPCQP_FLAG_WARM_SHIFT) ? 1 : 0;
-  hipError_t he = hipEventRecord(h->ev0, st);
-  if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
-  if (B > 0) {
-    if (h->cfg.dtype == MPCQP_DTYPE_F64) {
-      const FastIn<double> in = {(const double*)x0, nullptr, nullptr, nullptr, (const double*)mu, (const double*)ref,
-                                 (const double*)feet0, (const double*)footholds, gait, feet_id,
-                                 warm ? (const double*)u_out : nullptr, ys, shift};
-      he = wrench ? launch_wrench<double, true>(h, B, in, u_out, X_out, status, iters, res, st)
-                  : launch_fast<double, true>(h, B, in, u_out, X_out, status, iters, res, st);
-    } else {
-      const FastIn<float> in = {(const float*)x0, nullptr, nullptr, nullptr, (const float*)mu, (const float*)ref,
-                                (const float*)feet0, (const float*)footholds, gait, feet_id,
-                                warm ? (const float*)u_out : nullptr, ys, shift};
-      he = wrench ? launch_wrench<float, true>(h, B, in, u_out, X_out, status, iters, res, st)
-                  : launch_fast<float, true>(h, B, in, u_out, X_out, status, iters, res, st);
-    }
-    if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
+  if (hipEventRecord(h->ev0, st) != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord");
+  if (h->cfg.dtype == MPCQP_DTYPE_F64) {
+    const FastIn<double> in = {(const double*)x0, nullptr, nullptr, nullptr, (const double*)mu, (const double*)ref, (const double*)feet0,
+                               (const double*)footholds, gait, feet_id, nullptr, nullptr, 0};
+    hipLaunchKernelGGL((mpcqp_gait_expand_kernel<double>), grid, dim3(256), 0, st, in, h->cfg.delta, (int)N, B, (double*)r, contact, (double*)xdes);
+  } else {
+    const FastIn<float> in = {(const float*)x0, nullptr, nullptr, nullptr, (const float*)mu, (const float*)ref, (const float*)feet0,
+                              (const float*)footholds, gait, feet_id, nullptr, nullptr, 0};
+    hipLaunchKernelGGL((mpcqp_gait_expand_kernel<float>), grid, dim3(256), 0, st, in, h->cfg.delta, (int)N, B, (float*)r, contact, (float*)xdes);
   }
-  he = hipEventRecord(h->ev1, st);
-  if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
-  h->timed = true;
-  return MPCQP_OK;
+  const hipError_t he = hipGetLastError();
+  if (he != hipSuccess) return fail(h, MPCQP_EHIP, "gait expansion kernel launch", he);
+  h->ev0_set = true;   // the solve's timing starts in front of the expansion
+  return mpcqp_solve_batch(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, stream);
 }
 
 int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* u, const void* jac, void* tau, void* stream) {
@@ -508,6 +573,12 @@ int mpcqp_last_kernel_ms(mpcqp_handle h, float* ms) {
 extern "C" int mpcqp_debug_read_timeline(unsigned long long* out, int64_t B) {
   if (B > 65536) return MPCQP_EINVAL;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)B * 3 * sizeof(unsigned long long)) == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+}
+#endif
+#if defined(MPCQP_STAMPS) || defined(MPCQP_WDBG)
+int mpcqp_debug_read_wdbg(double* out2048) {
+  if (hipDeviceSynchronize() != hipSuccess) return MPCQP_EHIP;
+  return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_wdbg), 2048 * sizeof(double)) == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
 }
 #endif
 #ifdef MPCQP_STAMPS

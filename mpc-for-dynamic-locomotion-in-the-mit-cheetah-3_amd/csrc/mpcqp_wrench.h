@@ -76,6 +76,9 @@ template <int NW>
 __device__ __forceinline__ void wsync() {
   if constexpr (NW == 1) {   // one wave: its LDS operations execute in order; only the compiler has to be told
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef MPCQP_W_WAIT
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+#endif
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   } else {
@@ -544,7 +547,93 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
   wmax<1, NW>(q, s.red, tid);
   if (tid == 0) { s.gmax = q[0]; s.rho = (float)cfg.rho; s.iters = 0; s.psteps = 0; s.hard = 0; s.warm = 0; }
   wsync<NW>();
+#if defined(MPCQP_STAMPS) || defined(MPCQP_WDBG)
+  if (b == 0) {   // diagnostic build only: the first QP's setup products
+    for (int i = tid; i < n; i += NT) { g_wdbg[i] = (double)s.gl[i]; g_wdbg[1000 + i] = (double)s.rr[i]; }
+    for (int i = tid; i < NQ; i += NT) { g_wdbg[200 + i] = (double)s.gam[i]; g_wdbg[300 + i] = (double)s.e0P[i]; g_wdbg[400 + i] = (double)s.e0Q[i]; }
+    for (int i = tid; i < NL * 9; i += NT) g_wdbg[500 + i] = (double)s.Bl[i];
+    for (int i = tid; i < NL; i += NT) { g_wdbg[900 + i] = (double)s.cm[i]; g_wdbg[950 + i] = (double)s.ct[i]; }
+    if (tid == 0) { g_wdbg[1200] = (double)s.mu; g_wdbg[1201] = (double)s.gmax; g_wdbg[1202] = (double)s.cy; g_wdbg[1203] = (double)s.sy; }
+  }
+#endif
   return 0;
+}
+
+// Warm start (MPCQP_FLAG_WARM_START; the reference seeds every solve with its previous solution, src/mpc.py:270-271).  Same
+// contract as fast_warm_start in mpcqp_fast.h: the guess u0 (and the engine's record y0 of the previous solve's multipliers,
+// both moved up one stage with MPCQP_FLAG_WARM_SHIFT) becomes the start of the active-set iteration and of the ADMM block.
+// s.warm: 0 no guess (cold) | 1 primal guess only (unit multipliers on the rows it holds with equality) | 2 (u0, y0) is nearly
+// a KKT point | 3 (u0, y0) is only a neighbour.
+template <typename TV, typename TIO, int N>
+__device__ __forceinline__ void w_warm_start(SmemW<TV, N>& s, const WrTabs& tabs, const TIO* __restrict__ u0, const float* __restrict__ y0,
+                                             const int shift, const int tid) {
+  constexpr int n = WG<N>::n, NT = WG<N>::NT, NL = WG<N>::NL, NW = WG<N>::NW;
+  float amax[2] = {0.f, 0.f};
+  for (int i = tid; i < n; i += NT) {
+    const int k = min(i / 12 + shift, N - 1);
+    TV v = (TV)u0[k * 12 + i % 12];
+    if (!isfinite(v) || s.ct[i / 3] == 0) v = 0;          // swing feet carry no force (src/mpc.py:138-149)
+    s.uv[i] = v;
+    amax[0] = fmaxf(amax[0], fabsf((float)v));
+  }
+  for (int i = tid; i < NL * 5; i += NT) {                // the previous solve's multipliers, if the engine has them
+    float y = 0.f;
+    if (y0) {
+      const int L = i / 5, k = min(L / 4 + shift, N - 1);
+      y = y0[(k * 4 + L % 4) * 5 + i % 5];
+      if (!isfinite(y) || s.ct[L] == 0) y = 0.f;
+    }
+    s.ya[i] = y;
+    amax[1] = fmaxf(amax[1], fabsf(y));
+  }
+  wmax<2, NW>(amax, s.red, tid);
+  wsync<NW>();
+  if (!(amax[0] > 0.f)) {                                 // uniform: no guess
+    for (int i = tid; i < NL * 5; i += NT) s.ya[i] = 0.f;
+    for (int i = tid; i < n; i += NT) s.uv[i] = 0;
+    wsync<NW>();
+    return;
+  }
+  const bool duals = amax[1] > 0.f;
+  TV g3[3];
+  w_grad<TV, N>(s, tabs.K, tid, g3);                      // H u0 + g
+  float rs[1] = {0.f};
+  if (tid < NL) {
+    const int L = tid;
+    const bool stance = s.ct[L] != 0;
+    const TV mu = s.mu, flo = s.fmin, fhi = s.fmax;
+    const TV fx = s.uv[3 * L], fy = s.uv[3 * L + 1], fz = s.uv[3 * L + 2];
+    s.pu[3 * L] = fx; s.pu[3 * L + 1] = fy; s.pu[3 * L + 2] = fz;
+    s.ua[3 * L] = (float)fx; s.ua[3 * L + 1] = (float)fy; s.ua[3 * L + 2] = (float)fz;
+    const TV g[5] = {fz, fx - mu * fz, fx + mu * fz, fy - mu * fz, fy + mu * fz};
+    const TV tb = (TV)1e-3 * fmax(fabs(fz), (TV)1), tf = (TV)1e-3 * fmax(mu * fabs(fz), (TV)1);
+    TV y[5] = {0, 0, 0, 0, 0};
+    float z[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (stance) {
+      if (duals) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) y[i] = (TV)s.ya[5 * L + i];
+      } else {   // rows that u0 holds with equality get a unit multiplier of the right sign: the first polish step works on u0's own active set
+        y[0] = fz >= fhi - tb ? (TV)1 : (fz <= flo + tb ? (TV)-1 : (TV)0);
+        y[1] = g[1] >= -tf ? (TV)1 : (TV)0;  y[2] = g[2] <= tf ? (TV)-1 : (TV)0;
+        y[3] = g[3] >= -tf ? (TV)1 : (TV)0;  y[4] = g[4] <= tf ? (TV)-1 : (TV)0;
+      }
+      z[0] = (float)(fz < flo ? flo : (fz > fhi ? fhi : fz));
+      z[1] = (float)(g[1] > 0 ? (TV)0 : g[1]);  z[2] = (float)(g[2] < 0 ? (TV)0 : g[2]);
+      z[3] = (float)(g[3] > 0 ? (TV)0 : g[3]);  z[4] = (float)(g[4] < 0 ? (TV)0 : g[4]);
+      if (duals) {   // how good is (u0, y0)?  stationarity residual |H u0 + g + G'y0|
+        const float m = (float)mu;
+        const float rx = (float)g3[0] + (float)(y[1] + y[2]), ry = (float)g3[1] + (float)(y[3] + y[4]);
+        const float rz = (float)g3[2] + (float)y[0] + m * (float)(-y[1] + y[2] - y[3] + y[4]);
+        rs[0] = fmaxf(fmaxf(fabsf(rx), fabsf(ry)), fabsf(rz));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { s.py[5 * L + i] = y[i]; s.za[5 * L + i] = z[i]; if (!duals) s.ya[5 * L + i] = 0.f; }
+  }
+  wmax<1, NW>(rs, s.red, tid);
+  if (tid == 0) s.warm = !duals ? 1 : (rs[0] <= WARM_KKT_TOL * fmaxf(s.gmax, 1.f) ? 2 : 3);
+  wsync<NW>();
 }
 
 // ----------------------------------------------------------------------------------------------------- ADMM block
@@ -983,8 +1072,20 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
 #ifdef MPCQP_STAMPS
     const unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef MPCQP_LDS_POISON   // diagnostic build: every QP starts from an LDS block full of NaN patterns (finds reads of stale LDS)
+    {
+      unsigned* raw = reinterpret_cast<unsigned*>(&s);
+      for (int i = tid; i < (int)(sizeof(s) / 4); i += NT) raw[i] = 0xFFFFFFFFu;
+      wsync<NW>();
+    }
+#endif
     STAMP_INIT
-    if (w_setup<TV, TIO, N, GAIT>(s, cfg, tabs, in, b, tid, guard == 0)) {   // non-finite input -> zero outputs, status -1
+#ifdef MPCQP_LDS_POISON
+    const bool first_qp = true;
+#else
+    const bool first_qp = guard == 0;
+#endif
+    if (w_setup<TV, TIO, N, GAIT>(s, cfg, tabs, in, b, tid, first_qp)) {   // non-finite input -> zero outputs, status -1
       for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
       if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (size_t)(N + 1) * 13 + i] = (TIO)0;
       if (tid == 0) {
@@ -995,11 +1096,17 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       if (!ob.list) break;
       continue;
     }
+    if (in.u_init) w_warm_start<TV, TIO, N>(s, tabs, in.u_init + b * n, in.y_state ? in.y_state + b * (WG<N>::NL * 5) : nullptr, in.shift, tid);
     STAMP(0);
     const int max_iter = cfg.max_iter, polish_max = cfg.polish_max;
     int ok = 0;
+    const int warm = s.warm;
+    if (warm) {   // warm start: the guess's own active set first, no ADMM unless that fails
+      const int tries = warm == 1 ? WARM_POLISH : (warm == 2 ? 1 : 0);
+      for (int ps = 0; ps < polish_max && ps < tries && !ok; ++ps) ok = w_polish<TV, TP, N>(s, tabs, kinvP, tid);
+    }
     for (int round = 0; !ok; ++round) {
-      w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, 0, tid);
+      w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, (round == 0 && warm >= 2) ? WARM_K : 0, tid);
       const int budget = (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
       for (int ps = 0; ps < budget && !ok; ++ps) ok = w_polish<TV, TP, N>(s, tabs, kinvP, tid);
       if (ok || s.iters >= max_iter) break;

@@ -32,7 +32,7 @@ def main():
         batch = mk(B)
         t = time.time(); ref = oracle_solve(batch, N, 0.03); t_or = time.time() - t
         print(f"[{name}] oracle: {t_or:.1f}s status {np.bincount(ref['status'] + 1)}", flush=True)
-        precs = ("mixed", "f32", "f64") if N == 10 else ("mixed", "f32")
+        precs = ("mixed", "f32", "f64")
         for prec in precs:
             for io in ("f32", "f64"):
                 try:
