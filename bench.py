@@ -7,9 +7,10 @@ discretisation, condensing, matrix inversion, ADMM, polish) over one resident ba
 in HBM for the whole timed region.  N>1: the batch axis is sharded, one rank per GPU, no data-path collective
 (weak scaling: 4096 QPs per GPU); `--allgather` adds the optional RCCL all-gather of stage-0 GRFs.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the solve kernel against the fp32 matrix/vector peak with the
-ALGORITHMIC flop count of SURVEY.md section 8(d); `cpu_baseline` times the fp64 CPU oracle on a bounded sample
-of the same workload on the host cores (a reported baseline, not the target).
+Prints ONE JSON line (rank 0).  `roofline` prices the solve kernel against the packed-fp32 vector peak (the roof that
+binds: the path is neither HBM- nor MFMA-shaped) with the ALGORITHMIC flop count of SURVEY.md section
+8(d); `cpu_baseline` times the fp64 CPU oracle on a bounded sample of the same workload on the host cores, on one core and
+on all of them (a reported baseline, not the target; the reference's own CasADi + OSQP path cannot run offline).
 """
 import argparse
 import json
@@ -26,6 +27,7 @@ import mpcqp  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0        # HBM3E spec (6290 measured float4 copy)
+TRAFFIC_FILE = "r02_c_hbm_traffic.json"   # PMC passes of the current kernel (profiles/)
 
 
 def algorithmic_flops(N, K):
@@ -39,11 +41,7 @@ def algorithmic_bytes(N, elt=4):
     return (13 + 12 * N + 13 * (N + 1) + 1) * elt + 4 * N + 12 * N * elt + 8
 
 
-def cpu_baseline(batch, cfg_kw, sample):
-    """fp64 CPU oracle (oracle/, OpenMP over the batch) on the first `sample` QPs; same solver settings."""
-    path = os.path.join(REPO, "oracle", "libmpcqp_oracle.so")
-    if not os.path.exists(path):
-        return None
+def _host_cores():
     cores = len(os.sched_getaffinity(0))               # the threads OpenMP will actually get ...
     try:                                               # ... capped by the container's CPU quota (cgroup v2), if any
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -51,23 +49,73 @@ def cpu_baseline(batch, cfg_kw, sample):
             cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
     except (OSError, ValueError):
         pass
-    cores = min(cores, 64)
+    return min(cores, 64)
+
+
+def cpu_baseline(batch, cfg_kw, sample):
+    """fp64 CPU oracle (oracle/, OpenMP over the batch) on the first `sample` QPs; same solver settings.  All host cores
+    (the headline `value`) and one core; about 8 s of wall each."""
+    path = os.path.join(REPO, "oracle", "libmpcqp_oracle.so")
+    if not os.path.exists(path):
+        return None
+    import ctypes
+    cores = _host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)         # read by libgomp when the library is loaded below
     lib = mpcqp.Library(path)
     eng = mpcqp.Engine(lib, lib.default_config(**cfg_kw))
-    sub = {k: batch[k][:sample] for k in ("x0", "r", "contact", "xdes", "mu")}
-    eng.solve_batch_host(sub["x0"][:cores], sub["r"][:cores], sub["contact"][:cores], sub["xdes"][:cores], sub["mu"][:cores], want_X=False)
-    reps, dt, st = 0, 0.0, None
-    t0 = time.perf_counter()
-    while dt < 10.0 and reps < 64:                      # bounded: about 10 s of wall on the host cores
-        out = eng.solve_batch_host(sub["x0"], sub["r"], sub["contact"], sub["xdes"], sub["mu"], want_X=False)
-        reps += 1
-        dt = time.perf_counter() - t0
-        st = out["status"]
-    return {"value": reps * sample / dt, "unit": "QP solves/s", "cores": cores, "kind": "port",
+    try:
+        set_threads = ctypes.CDLL("libgomp.so.1").omp_set_num_threads
+    except OSError:
+        set_threads = None
+
+    def timed(n_threads, n_qp, budget):
+        if set_threads is not None:
+            set_threads(int(n_threads))
+        sub = {k: batch[k][:n_qp] for k in ("x0", "r", "contact", "xdes", "mu")}
+        eng.solve_batch_host(sub["x0"][:n_threads], sub["r"][:n_threads], sub["contact"][:n_threads], sub["xdes"][:n_threads],
+                             sub["mu"][:n_threads], want_X=False)
+        reps, dt, st = 0, 0.0, None
+        t0 = time.perf_counter()
+        while dt < budget and reps < 64:
+            out = eng.solve_batch_host(sub["x0"], sub["r"], sub["contact"], sub["xdes"], sub["mu"], want_X=False)
+            reps += 1
+            dt = time.perf_counter() - t0
+            st = out["status"]
+        return reps * n_qp / dt, reps, dt, float(((st == 1) | (st == 2)).mean())
+
+    v_all, reps, dt, solved = timed(cores, sample, 8.0)
+    one = None
+    if set_threads is not None:
+        v_one, reps1, dt1, _ = timed(1, max(32, sample // 16), 8.0)
+        one = {"value": v_one, "cores": 1, "sample": f"first {max(32, sample // 16)} QPs x {reps1} passes, {dt1:.1f} s wall"}
+    return {"value": v_all, "unit": "QP solves/s", "cores": cores, "kind": "port", "one_core": one,
+            "reference_osqp_path": "unavailable offline: casadi / osqp / dartpy are absent from the image and cannot be installed "
+                                   "(SURVEY.md section 8c); the reference's own published figure is 61 Hz per solve at N = 60 (BASELINE.md)",
             "sample": f"first {sample} QPs of the same batch x {reps} passes, fp64 condensed OSQP-style ADMM + polish (same rho/sigma/"
-                      f"relax/iteration cap as the GPU run), OpenMP over the batch, {dt:.1f} s wall; solved fraction "
-                      f"{float(((st == 1) | (st == 2)).mean()):.3f}"}
+                      f"relax/iteration cap as the GPU run), OpenMP over the batch, {dt:.1f} s wall; solved fraction {solved:.3f}"}
+
+
+def gait_breakdown(solver, N, delta, B, steps=5):
+    """Secondary figures on the same engine: single-gait batches and a true 4-contact batch (all feet down on all stages)."""
+    out = {}
+    cases = [(g, (g,), None) for g in ("trot", "pronk", "amble", "gallop")] + [("all_stance", ("trot",), 1)]
+    for name, gaits, force_contact in cases:
+        b = mpcqp.synth.make_batch(B, N, delta, 20250809, gaits, (0.3, 0.5, 0.7, 1.0))
+        if force_contact is not None:
+            b["contact"][:] = 1
+        dev = solver.upload(b)
+        for _ in range(2):
+            o = solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            o = solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+        e1.record()
+        torch.cuda.synchronize()
+        st = o["status"].cpu().numpy()
+        out[name] = {"qp_per_s": B * steps / (e0.elapsed_time(e1) * 1e-3), "solved_fraction": float(((st == 1) | (st == 2)).mean())}
+    return out
 
 
 def main():
@@ -80,6 +128,7 @@ def main():
     ap.add_argument("--allgather", action="store_true", help="all-gather stage-0 GRFs over RCCL every step")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true", help="skip the secondary per-gait / all-stance figures")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,18 +174,20 @@ def main():
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record()                       # same stream the engine launches on (torch's current stream)
-    for _ in range(args.steps):
+    evs[0].record()                    # same stream the engine launches on (torch's current stream)
+    for i in range(args.steps):
         out = step()
-    ev1.record()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps       # average launch duration over the timed region
+    kernel_ms = evs[0].elapsed_time(evs[-1]) / args.steps       # average launch duration over the timed region
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2]
     last_ms = solver.last_kernel_ms()                    # engine's own event pair around the last launch
     if dist:
         t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=sync_device)
@@ -157,16 +208,19 @@ def main():
         flops = algorithmic_flops(N, k_mean)
         achieved = flops * B / (kernel_ms * 1e-3) / 1e12
         hbm = algorithmic_bytes(N) * B / (kernel_ms * 1e-3) / 1e9
-        traffic = None     # HBM bytes per launch from the committed PMC passes (tools/pmc_hbm.sh), same workload only
+        # HBM bytes per launch: NOT measured in this run (PMC counters need their own rocprofv3 passes, tools/pmc_hbm.sh); the
+        # figure is read from the committed summary of those passes on this same workload and kernel, and says so
+        traffic, traffic_src = None, None
         try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "r01_h_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(REPO, "profiles", TRAFFIC_FILE)))
             if B == 4096 and args.precision == "mixed":
-                traffic = tj["hbm_bytes_per_launch"]
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/" + TRAFFIC_FILE
         except (OSError, ValueError, KeyError):
             pass
         line = {
             "metric": "QP solves/sec (horizon=10, 4-contact Lite3) at batch=4096", "value": value, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_median": median_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "mixed": "f32 tiles + f64 residuals", "f64": "f64"}[args.precision],
             "data": "synthetic",
@@ -175,10 +229,12 @@ def main():
                        "precision": args.precision, "admm_block": int(solver.cfg.check_every), "max_iter": int(solver.cfg.max_iter),
                        "polish": bool(solver.cfg.flags & 1), "allgather": bool(gathered is not None),
                        "solved_fraction": solved, "admm_iters_mean": k_mean, "polish_steps_mean": float((iters // 1000).mean())},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
-                         "kernel": "mpcqp_fast_solve<double,float> (one launch per solve_batch, after a 5 us ordering pre-pass; both inside kernel_ms)" if args.precision == "mixed"
-                         else "mpcqp_fast_solve<float,float>" if args.precision == "f32" else "mpcqp_solve_kernel<double,double,float,10>",
+            "roofline": {"bound": "valu_fp32", "bound_note": "packed-fp32 vector peak (v_pk_fma_f32; numerically the fp32 MFMA peak of the "
+                         "guide): the kernel has no GEMM-shaped work and 1.6 KB of compulsory HBM traffic per QP",
+                         "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "mpcqp_wrench_solve<double,float,double> (one launch per solve_batch, after a 5 us ordering pre-pass; both inside kernel_ms)" if args.precision == "mixed"
+                         else "mpcqp_fast_solve<float,float>" if args.precision == "f32" else "mpcqp_wrench_solve<double,double,double>",
                          "kernel_ms": kernel_ms, "kernel_ms_last_launch": last_ms,
                          "algorithmic_flops_per_qp": flops,
                          "hbm": {"achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS,
@@ -192,6 +248,8 @@ def main():
                               min(args.cpu_sample, B))
             if cb:
                 line["cpu_baseline"] = cb
+        if world == 1 and not args.no_breakdown:
+            line["breakdown"] = gait_breakdown(solver, N, delta, B)
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -312,8 +312,10 @@ static bool build_wrench_tables(mpcqp_engine* e, const double* tab /* c0 | c1 */
           const int R = 8 * gr + r, C = 8 * gc + cc;
           double v = 0.0;
           if (R < NQ && C < NQ && R % 6 == C % 6) v = Ki[(R % 6) * N * N + (R / 6) * N + (C / 6)];
-          t64[(size_t)(8 * r + cc) * NT + tid] = v;
-          t32[(size_t)(8 * r + cc) * NT + tid] = (float)v;
+          if (R >= NQ && R == C) v = 1.0;   // identity on the padding: the sweep pivots on all 8 G rows
+          // [16-byte group][lane][element]: fp32 groups of 4 (row r, columns 4 h ..), fp64 groups of 2 (row r, columns 2 h ..)
+          t64[((size_t)(4 * r + cc / 2) * NT + tid) * 2 + cc % 2] = v;
+          t32[((size_t)(2 * r + cc / 4) * NT + tid) * 4 + cc % 4] = (float)v;
         }
     }
     hipError_t he = hipMalloc((void**)&e->wr_K, sizeof(double) * 6 * N * N);

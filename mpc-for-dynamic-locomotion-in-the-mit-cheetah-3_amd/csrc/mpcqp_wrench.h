@@ -49,16 +49,20 @@ struct SmemW {
   TV rzw0[3];
   TV wP[6], wQ[6];
   TV delta, theta, alpha, inv_m, fmin, fmax;
-  TV rr[Geo::n];                 // lever arms
   TV Bl[Geo::NL * 9];            // per leg-stage: Rz Ihat^-1 [r]x, masked by contact (row i = angular component, col a = force axis)
   TV cm[Geo::NL];                // contact / m
-  TV e0P[Geo::NQ], e0Q[Geo::NQ]; // free response - target, stage k = j + 1 at [6 j + q]: P = (Theta, p), Q = (Rz omega, v)
   TV gam[Geo::NQ];               // gradient of the cost in wrench space at u = 0
   TV gl[Geo::n];                 // linear term g = T' gam
-  TV uv[Geo::n], gv[Geo::n];     // point / gradient of the structured gradient
+  TV uv[Geo::n];                 // point of the structured gradient (the gradient itself comes back in registers)
   TV ww[Geo::NQ], kap[Geo::NQ];  // wrench of uv, K ww + gam
-  TV pu[Geo::n], py[Geo::NL * 5];
-  float ua[Geo::n], za[Geo::NL * 5], ya[Geo::NL * 5];   // last ADMM iterate (ya = multipliers, unscaled)
+  union {   // the staged inputs are dead once setup has built B_l and the free response: they share the bytes of the polish iterate
+    struct { TV pu[Geo::n], py[Geo::NL * 5]; };
+    struct { TV rr[Geo::n]; TV xd[(N + 1) * 13]; };   // lever arms, x_des
+  };
+  union {   // ... and the free response (minus target) those of the ADMM iterate
+    struct { float ua[Geo::n], za[Geo::NL * 5], ya[Geo::NL * 5]; };   // last ADMM iterate (ya = multipliers, unscaled)
+    struct { TV e0P[Geo::NQ], e0Q[Geo::NQ]; };   // stage k = j + 1 at [6 j + q]: P = (Theta, p), Q = (Rz omega, v)
+  };
   alignas(16) double E[N * 36];                          // T D^-1 T' blocks (TM-typed view)
   alignas(16) double piv[2 * Geo::DP];                   // pivot-row broadcast (TM-typed view)
   alignas(16) double bv[Geo::DP], cv[Geo::DP];           // mat-vec in / out (TM-typed view)
@@ -207,26 +211,41 @@ __device__ __forceinline__ void tilemv(const WTile<double>& t, const double (&x)
 }
 
 // tile <- K^-1 (constant, tile layout in global memory) + E (block diagonal, 6 x 6 per stage, in LDS).
+// Pass 1 loads the lane's 64 K^-1 entries straight into the tile registers as 16-byte coalesced loads, all in flight at once
+// (layout [16 B group][lane]: fp32 group g = row g / 2, columns 4 (g % 2) ..; fp64 group g = row g / 4, columns 2 (g % 4) ..).
+// Pass 2 adds E: entry (R, C) of stage j = R / 6 sits at E[6 R + C - 6 j] and exists iff 0 <= C - 6 j < 6, i.e. for tile
+// column c iff (c - lo) <u 6 with lo = 6 j - 8 gc per tile row; reads outside a row's run are masked (LDS reads never fault).
 template <typename TM, int N>
 __device__ __forceinline__ void w_tile_init(WTile<TM>& t, const TM* __restrict__ kinvT, const TM* __restrict__ E, int gr, int gc, int tid) {
   constexpr int NT = WG<N>::NT, NQ = WG<N>::NQ;
-  // (opaque copies: the index arithmetic below is invariant across the QPs of a resident wave, and hoisted out of the QP
-  //  loop its ~200 masks and addresses would occupy -- and spill -- registers for the whole kernel)
-  asm volatile("" : "+v"(gr), "+v"(gc), "+v"(tid));
-  int cst[8], cof[8];   // stage / offset-in-stage of my eight columns
+  asm volatile("" : "+v"(gr), "+v"(gc), "+v"(tid));   // (opaque: keeps the per-lane index arithmetic out of the enclosing loops' preheaders)
+  if constexpr (sizeof(TM) == 4) {
+    const float4* k4 = reinterpret_cast<const float4*>(kinvT);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { const int C = 8 * gc + c; cst[c] = C / 6; cof[c] = C - 6 * cst[c]; }
+    for (int g = 0; g < 16; ++g) {
+      const float4 v = k4[(size_t)g * NT + tid];
+      t.v[g / 2][2 * (g % 2)] = mk2(v.x, v.y);
+      t.v[g / 2][2 * (g % 2) + 1] = mk2(v.z, v.w);
+    }
+  } else {
+    const double2* k2 = reinterpret_cast<const double2*>(kinvT);
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+      const double2 v = k2[(size_t)g * NT + tid];
+      t.v[g / 4][2 * (g % 4)] = v.x;
+      t.v[g / 4][2 * (g % 4) + 1] = v.y;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    asm volatile("" ::: "memory");   // one row's loads in flight at a time (the tile itself is most of the register file in fp64)
-    const int R = 8 * gr + r, jR = R / 6, qR = R - 6 * jR;
-    const int base = 36 * jR + 6 * qR;
+    const int R = 8 * gr + r, jR = (R * 43) >> 8;            // R / 6 for R < 128
+    const int lo = 6 * jR - 8 * gc;
+    const int base = R < NQ ? 6 * R - lo : -(1 << 20);         // rows of the padding read nothing
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const bool in = (cst[c] == jR) && (R < NQ);
-      const TM e = E[in ? base + cof[c] : 0];
-      const TM k = kinvT[(size_t)(8 * r + c) * NT + tid];
-      tset(t, r, c, k + (in ? e : (TM)0));
+      const bool in = (unsigned)(c - lo) < 6u && R < NQ;
+      const TM e = E[base + c];
+      tset(t, r, c, tget(t, r, c) + (in ? e : (TM)0));
     }
   }
 }
@@ -235,12 +254,12 @@ __device__ __forceinline__ void w_tile_init(WTile<TM>& t, const TM* __restrict__
 // symmetry the same vector serves as the pivot column.  One LDS broadcast per pivot; no barrier when the QP is one wave.
 template <typename TM, int N>
 __device__ __forceinline__ void w_sweep(WTile<TM>& t, TM* __restrict__ piv, int gr, int gc) {
-  constexpr int NQ = WG<N>::NQ, NW = WG<N>::NW, DP = WG<N>::DP, NB = WG<N>::NB;
+  constexpr int NW = WG<N>::NW, DP = WG<N>::DP, G = WG<N>::G;
   int step = 0;
-  for (int og = 0; og < NB; ++og) {
+  for (int og = 0; og < G; ++og) {
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      if (8 * og + rr >= NQ) break;   // uniform
+      if (8 * og + rr >= WG<N>::NQ) break;   // uniform; the padding rows carry an identity block and need no pivot
       TM* vb = piv + (NW > 1 ? (step & 1) * DP : 0);
       if (gr == og) {
         TM row[8];
@@ -258,6 +277,8 @@ __device__ __forceinline__ void w_sweep(WTile<TM>& t, TM* __restrict__ piv, int 
 #pragma unroll
       for (int i = 0; i < 8; ++i) { vr[i] *= p; m[i] = vr[i]; }
       // the owner's pivot row becomes p * row: its tile row IS the published row, so the multiplier 1 - p does it
+      // (the same trick on the pivot column -- multiplier 1 / p - 1 on the published pivot element -- costs eps / p relative on
+      //  the column entries, which the alpha = 1e-4 polish systems do not survive: measured, tests/test_gpu_parity.py)
       m[rr] = prow ? (TM)1 - p : vr[rr];
       rank1(t, m, vc);
 #pragma unroll
@@ -358,49 +379,34 @@ __device__ __forceinline__ void w_solve(const WTile<TM>& t, const LegSys<TM>& L,
 }
 
 // ----------------------------------------------------------------------------------------------------- inputs
-template <typename TIO, bool GAIT>
-__device__ __forceinline__ double w_xdes(const FastIn<TIO>& in, double delta, size_t b, int N, int k, int c) {
-  if constexpr (!GAIT) {
-    return (double)in.xdes[b * (size_t)(N + 1) * 13 + k * 13 + c];
-  } else {   // src/mpc.py:202-214
-    const TIO* ref = in.ref + b * 10;
-    if (c < 2) return (double)ref[c];
-    if (c == 2) return (double)ref[2] + (double)k * delta * (double)ref[9];
-    if (c < 6) return (double)ref[c] + (double)k * delta * (double)ref[6 + (c - 3)];
-    if (c < 8) return 0.0;
-    if (c == 8) return (double)ref[9];
-    if (c < 12) return (double)ref[6 + (c - 9)];
-    return (double)in.x0[b * 13 + 12];
-  }
-}
-
-// Operator tuple / gait descriptors -> LDS (x0, lever arms, contact, mu); returns the per-thread non-finite flag.
-template <typename TV, typename TIO, int N, bool GAIT>
-__device__ __forceinline__ int w_load(SmemW<TV, N>& s, const FastIn<TIO>& in, const DevCfg& cfg, size_t b, int tid) {
-  constexpr int NT = WG<N>::NT, n = WG<N>::n, NL = WG<N>::NL;
+// Operator tuple (src/mpc.py:242-255) -> LDS (x0, lever arms, contact, x_des, mu): every global load of the QP is issued before
+// the first one is consumed; returns the per-thread non-finite flag.
+template <typename TV, typename TIO, int N>
+__device__ __forceinline__ int w_load(SmemW<TV, N>& s, const FastIn<TIO>& in, size_t b, int tid) {
+  constexpr int NT = WG<N>::NT, n = WG<N>::n, NL = WG<N>::NL, NX = (N + 1) * 13;
+  constexpr int RX = (NX + NT - 1) / NT, RR = (n + NT - 1) / NT, RC = (NL + NT - 1) / NT;
+  TIO vx[RX], vr[RR], v0 = 0, vm = 0;
+  uint8_t vc[RC];
+  const TIO* xp = in.xdes + b * (size_t)NX;
+  const TIO* rp = in.r + b * (size_t)n;
+  const uint8_t* cp = in.contact + b * (size_t)NL;
+#pragma unroll
+  for (int q = 0; q < RX; ++q) { const int i = tid + q * NT; vx[q] = i < NX ? xp[i] : (TIO)0; }
+#pragma unroll
+  for (int q = 0; q < RR; ++q) { const int i = tid + q * NT; vr[q] = i < n ? rp[i] : (TIO)0; }
+#pragma unroll
+  for (int q = 0; q < RC; ++q) { const int i = tid + q * NT; vc[q] = i < NL ? cp[i] : (uint8_t)0; }
+  if (tid < 13) v0 = in.x0[b * 13 + tid];
+  if (tid == 0) vm = in.mu[b];
   int bad = 0;
-  for (int i = tid; i < 13; i += NT) { const TV v = (TV)in.x0[b * 13 + i]; s.x0[i] = v; bad |= !isfinite(v); }
-  for (int i = tid; i < (N + 1) * 13; i += NT) bad |= !isfinite(w_xdes<TIO, GAIT>(in, cfg.delta, b, N, i / 13, i % 13));
-  if constexpr (!GAIT) {
-    for (int i = tid; i < n; i += NT) { const TV v = (TV)in.r[b * n + i]; s.rr[i] = v; bad |= !isfinite(v); }
-    for (int i = tid; i < NL; i += NT) s.ct[i] = in.contact[b * NL + i] ? 1 : 0;
-  } else {   // src/mpc.py:218-254 with the planner queries of src/footstep_planner.py:226-246 (see fast_load_gait)
-    const TV d = (TV)cfg.delta;
-    const int tis = in.gait[b * 4 + 0], ss = in.gait[b * 4 + 1], ds = in.gait[b * 4 + 2];
-    const TIO* ref = in.ref + b * 10;
-    for (int i = tid; i < n; i += NT) {
-      const int k = i / 12, l = (i % 12) / 3, a = i % 3;
-      int tau = tis + k, st = 0;
-      if (tau >= ss + ds) { tau -= ss + ds; st = 1; }
-      TV v;
-      if (k == 0) v = (TV)in.feet0[b * 12 + l * 3 + a] - (TV)in.x0[b * 13 + 3 + a];
-      else v = (TV)in.footholds[b * 24 + st * 12 + l * 3 + a] - ((TV)ref[3 + a] + (TV)k * d * (TV)ref[6 + a]);
-      s.rr[i] = v;
-      bad |= !isfinite(v);
-      if (a == 0) s.ct[k * 4 + l] = (tau < ss) ? (in.feet_id[b * 8 + st * 4 + l] ? 1 : 0) : 1;
-    }
-  }
-  if (tid == 0) { const TV m = (TV)in.mu[b]; s.mu = m; bad |= !isfinite(m); }
+#pragma unroll
+  for (int q = 0; q < RX; ++q) { const int i = tid + q * NT; if (i < NX) { s.xd[i] = (TV)vx[q]; bad |= !isfinite(vx[q]); } }
+#pragma unroll
+  for (int q = 0; q < RR; ++q) { const int i = tid + q * NT; if (i < n) { s.rr[i] = (TV)vr[q]; bad |= !isfinite(vr[q]); } }
+#pragma unroll
+  for (int q = 0; q < RC; ++q) { const int i = tid + q * NT; if (i < NL) s.ct[i] = vc[q] ? 1 : 0; }
+  if (tid < 13) { s.x0[tid] = (TV)v0; bad |= !isfinite(v0); }
+  if (tid == 0) { s.mu = (TV)vm; bad |= !isfinite(vm); }
   return bad;
 }
 
@@ -409,7 +415,17 @@ __device__ __forceinline__ int w_load(SmemW<TV, N>& s, const FastIn<TIO>& in, co
 template <typename TV, int N>
 __device__ __forceinline__ void w_grad(SmemW<TV, N>& s, const double* __restrict__ Ktab, int tid, TV (&gr)[3]) {
   constexpr int NL = WG<N>::NL, NQ = WG<N>::NQ, NW = WG<N>::NW, NT = WG<N>::NT;
+  static_assert(NQ <= NT, "one wrench component per lane");
   const int L = min(tid, NL - 1);
+  // this lane's row of K_q, requested first: its L2 latency hides behind the wrench phase
+  const int e = min(tid, NQ - 1), ej = e / 6, eq = e - 6 * ej;
+  constexpr bool EARLY = N <= 10;   // (twenty doubles more next to the fp64 tile would spill)
+  const double2* K2 = reinterpret_cast<const double2*>(Ktab + ((size_t)eq * N + ej) * N);
+  double Kr[N];
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int h = 0; h < N / 2; ++h) { const double2 v = K2[h]; Kr[2 * h] = v.x; Kr[2 * h + 1] = v.y; }
+  }
   TV f[3], B[9];
 #pragma unroll
   for (int a = 0; a < 3; ++a) f[a] = s.uv[3 * L + a];
@@ -428,13 +444,15 @@ __device__ __forceinline__ void w_grad(SmemW<TV, N>& s, const double* __restrict
     }
   }
   wsync<NW>();
-  for (int e = tid; e < NQ; e += NT) {
-    const int j = e / 6, q = e - 6 * j;
-    const double* Kr = Ktab + ((size_t)q * N + j) * N;
+  {
+    if constexpr (!EARLY) {
+#pragma unroll
+      for (int h = 0; h < N / 2; ++h) { const double2 v = K2[h]; Kr[2 * h] = v.x; Kr[2 * h + 1] = v.y; }
+    }
     TV acc = s.gam[e];
 #pragma unroll
-    for (int jp = 0; jp < N; ++jp) acc = fma((TV)Kr[jp], s.ww[6 * jp + q], acc);
-    s.kap[e] = acc;
+    for (int jp = 0; jp < N; ++jp) acc = fma((TV)Kr[jp], s.ww[6 * jp + eq], acc);
+    if (tid < NQ) s.kap[e] = acc;
   }
   wsync<NW>();
   {
@@ -446,14 +464,13 @@ __device__ __forceinline__ void w_grad(SmemW<TV, N>& s, const double* __restrict
 #pragma unroll
       for (int i = 0; i < 3; ++i) g = fma(B[3 * i + a], kj[i], g);
       gr[a] = g;
-      if (tid < NL) s.gv[3 * L + a] = g;
     }
   }
   wsync<NW>();
 }
 
 // Per-QP setup: constants (once per workgroup), inputs, B_l, free response, gam, g, |g|_inf, cold ADMM state.
-template <typename TV, typename TIO, int N, bool GAIT>
+template <typename TV, typename TIO, int N>
 __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const WrTabs& tabs, const FastIn<TIO>& in, size_t b, int tid,
                                        bool first) {
   constexpr int NT = WG<N>::NT, NL = WG<N>::NL, NQ = WG<N>::NQ, n = WG<N>::n, NW = WG<N>::NW, DP = WG<N>::DP;
@@ -465,7 +482,7 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
     }
     for (int i = tid; i < DP; i += NT) { s.bv[i] = 0.0; s.cv[i] = 0.0; s.piv[i] = 0.0; s.piv[DP + i] = 0.0; }   // pad slots stay finite
   }
-  int bad = w_load<TV, TIO, N, GAIT>(s, in, cfg, b, tid);
+  int bad = w_load<TV, TIO, N>(s, in, b, tid);
   if constexpr (NW == 1) {
     bad = __any(bad) ? 1 : 0;
   } else {
@@ -503,24 +520,25 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
     s.cm[L] = st ? s.inv_m : (TV)0;
   }
   // free response minus target, stages k = 1..N (closed forms: mpcqp_device.h struct_grad)
-  for (int e = tid; e < NQ; e += NT) {
-    const int j = e / 6, q = e - 6 * j, k = j + 1;
+  TV eP = 0, eQ = 0;
+  if (tid < NQ) {
+    const int e = tid, j = e / 6, q = e - 6 * j, k = j + 1;
     const TV d = s.delta, th = s.theta, g = s.x0[12], kd = (TV)k * d;
-    TV eP, eQ;
+    const TV* xk = s.xd + 13 * k;
     if (q < 3) {
-      eP = s.x0[q] + kd * s.rzw0[q] - (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, q);
-      const TV wx = (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, 6), wy = (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, 7),
-               wz = (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, 8);
+      eP = s.x0[q] + kd * s.rzw0[q] - xk[q];
+      const TV wx = xk[6], wy = xk[7], wz = xk[8];
       const TV rd = q == 0 ? s.cy * wx - s.sy * wy : (q == 1 ? s.sy * wx + s.cy * wy : wz);
       eQ = s.rzw0[q] - rd;
     } else {
       const int a = q - 3;
-      eP = s.x0[3 + a] + kd * s.x0[9 + a] - (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, 3 + a);
-      eQ = s.x0[9 + a] - (TV)w_xdes<TIO, GAIT>(in, cfg.delta, b, N, k, 9 + a);
+      eP = s.x0[3 + a] + kd * s.x0[9 + a] - xk[3 + a];
+      eQ = s.x0[9 + a] - xk[9 + a];
       if (a == 2) { eP += d * d * g * ((TV)(k * (k - 1)) * (TV)0.5 + th * (TV)k); eQ += kd * g; }
     }
-    s.e0P[e] = eP; s.e0Q[e] = eQ;
   }
+  wsync<NW>();   // everyone has read the staged inputs (rr, xd): their bytes may be reused
+  if (tid < NQ) { s.e0P[tid] = eP; s.e0Q[tid] = eQ; }
   wsync<NW>();
   for (int e = tid; e < NQ; e += NT) {   // gam_jq = 2 sum_{k>j} [wP d^2 (k-1-j+th) eP_kq + wQ d eQ_kq]
     const int j = e / 6, q = e - 6 * j;
@@ -534,23 +552,30 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
     }
     s.gam[e] = (TV)2 * (s.wP[q] * d * d * aP + s.wQ[q] * d * aQ);
   }
+  wsync<NW>();   // the free response has been consumed: its bytes become the ADMM iterate
   for (int i = tid; i < n; i += NT) { s.uv[i] = 0; s.ua[i] = 0.f; s.pu[i] = 0; }
   for (int i = tid; i < NL * 5; i += NT) { s.za[i] = 0.f; s.ya[i] = 0.f; s.py[i] = 0; }
   wsync<NW>();
-  TV g3[3];
-  w_grad<TV, N>(s, tabs.K, tid, g3);   // gradient at u = 0 = linear term
   float q[1] = {0.f};
-  if (tid < NL) {
+  if (tid < NL) {   // linear term g = T' gam (the gradient at u = 0)
+    const TV* gj = s.gam + 6 * (tid >> 2);
+    const TV cm = s.cm[tid];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { s.gl[3 * tid + a] = g3[a]; q[0] = fmaxf(q[0], fabsf((float)g3[a])); }
+    for (int a = 0; a < 3; ++a) {
+      TV g = cm * gj[3 + a];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) g = fma(s.Bl[9 * tid + 3 * i + a], gj[i], g);
+      s.gl[3 * tid + a] = g;
+      q[0] = fmaxf(q[0], fabsf((float)g));
+    }
   }
   wmax<1, NW>(q, s.red, tid);
   if (tid == 0) { s.gmax = q[0]; s.rho = (float)cfg.rho; s.iters = 0; s.psteps = 0; s.hard = 0; s.warm = 0; }
   wsync<NW>();
 #if defined(MPCQP_STAMPS) || defined(MPCQP_WDBG)
   if (b == 0) {   // diagnostic build only: the first QP's setup products
-    for (int i = tid; i < n; i += NT) { g_wdbg[i] = (double)s.gl[i]; g_wdbg[1000 + i] = (double)s.rr[i]; }
-    for (int i = tid; i < NQ; i += NT) { g_wdbg[200 + i] = (double)s.gam[i]; g_wdbg[300 + i] = (double)s.e0P[i]; g_wdbg[400 + i] = (double)s.e0Q[i]; }
+    for (int i = tid; i < n; i += NT) g_wdbg[i] = (double)s.gl[i];
+    for (int i = tid; i < NQ; i += NT) g_wdbg[200 + i] = (double)s.gam[i];
     for (int i = tid; i < NL * 9; i += NT) g_wdbg[500 + i] = (double)s.Bl[i];
     for (int i = tid; i < NL; i += NT) { g_wdbg[900 + i] = (double)s.cm[i]; g_wdbg[950 + i] = (double)s.ct[i]; }
     if (tid == 0) { g_wdbg[1200] = (double)s.mu; g_wdbg[1201] = (double)s.gmax; g_wdbg[1202] = (double)s.cy; g_wdbg[1203] = (double)s.sy; }
@@ -646,37 +671,51 @@ struct LegAdmm {
   TM mu;
 };
 
-template <typename TV, typename TM, int N>
-__device__ __forceinline__ float w_ratio(SmemW<TV, N>& s, const WrTabs& tabs, const LegAdmm<TM>& A, float rho, bool leg, int tid) {
+// OSQP's rho-adaptation ratio sqrt((|r_prim| / norm_prim) / (|r_dual| / norm_dual)) of the ADMM iterate (u, z, y): one
+// structured gradient for H u + g, the rest per leg.  Uniform result.
+template <typename TV, int N>
+__device__ __forceinline__ float w_ratio(SmemW<TV, N>& s, const WrTabs& tabs, const float (&u)[3], const float (&z)[5], const float (&y)[5],
+                                         const float (&g)[3], const float mu, const bool leg, const int tid) {
   constexpr int NL = WG<N>::NL, NW = WG<N>::NW;
   if (tid < NL) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) s.uv[3 * tid + a] = (TV)A.u[a];
+    for (int a = 0; a < 3; ++a) s.uv[3 * tid + a] = (TV)u[a];
   }
   wsync<NW>();
   TV hv[3];
   w_grad<TV, N>(s, tabs.K, tid, hv);
   float q[4] = {0.f, 0.f, 0.f, 0.f};
   if (leg) {
-    const float mu = (float)A.mu, fx = (float)A.u[0], fy = (float)A.u[1], fz = (float)A.u[2], m = mu * fz;
-    const float gu[5] = {fz, fx - m, fx + m, fy - m, fy + m};
-    float y[5];
+    const float m = mu * u[2];
+    const float gu[5] = {u[2], u[0] - m, u[0] + m, u[1] - m, u[1] + m};
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      y[i] = rho * (float)A.yh[i];
-      q[0] = fmaxf(q[0], fabsf(gu[i] - (float)A.z[i]));
-      q[2] = fmaxf(q[2], fmaxf(fabsf(gu[i]), fabsf((float)A.z[i])));
+      q[0] = fmaxf(q[0], fabsf(gu[i] - z[i]));
+      q[2] = fmaxf(q[2], fmaxf(fabsf(gu[i]), fabsf(z[i])));
     }
     const float Gy[3] = {y[1] + y[2], y[3] + y[4], y[0] + mu * (-y[1] + y[2] - y[3] + y[4])};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       q[1] = fmaxf(q[1], fabsf((float)hv[a] + Gy[a]));
-      q[3] = fmaxf(q[3], fmaxf(fabsf((float)hv[a] - (float)A.g[a]), fabsf(Gy[a])));
+      q[3] = fmaxf(q[3], fmaxf(fabsf((float)hv[a] - g[a]), fabsf(Gy[a])));
     }
   }
   wmax<4, NW>(q, s.red, tid);
   const float sp = q[2], sd = fmaxf(q[3], s.gmax);
   return sqrtf((q[0] / fmaxf(sp, 1e-12f)) / fmaxf(q[1] / fmaxf(sd, 1e-12f), 1e-30f));
+}
+
+// The same for the iterate the last ADMM block left in LDS (only needed when its polish steps failed).
+template <typename TV, int N>
+__device__ __forceinline__ float w_ratio_lds(SmemW<TV, N>& s, const WrTabs& tabs, const int tid0) {
+  constexpr int NL = WG<N>::NL;
+  const int tid = opaque(tid0), L = min(tid, NL - 1);
+  float u[3], z[5], y[5], g[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { u[a] = s.ua[3 * L + a]; g[a] = (float)s.gl[3 * L + a]; }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { z[i] = s.za[5 * L + i]; y[i] = s.ya[5 * L + i]; }
+  return w_ratio<TV, N>(s, tabs, u, z, y, g, (float)s.mu, tid < NL, tid);
 }
 
 #ifndef MPCQP_W_ADAPT_AT
@@ -776,9 +815,15 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
         }
         it = seg_end;
         STAMP(4);
-        ratio = w_ratio<TV, TM, N>(s, tabs, A, rho, leg, tid);   // OSQP's residual ratio at the end of the segment
-        STAMP(5);
         if (it >= K) break;
+        {   // the single early rho check: OSQP's residual ratio after the first ADAPT_AT iterations
+          const float u3[3] = {(float)A.u[0], (float)A.u[1], (float)A.u[2]}, g3[3] = {(float)A.g[0], (float)A.g[1], (float)A.g[2]};
+          float z5[5], y5[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) { z5[k] = (float)A.z[k]; y5[k] = rho * (float)A.yh[k]; }
+          ratio = w_ratio<TV, N>(s, tabs, u3, z5, y5, g3, (float)A.mu, leg, tid);
+        }
+        STAMP(5);
         if (ratio > ADAPT_THR) { rebuild = true; break; }        // uniform: slowly converging QP -> larger penalty, rebuilt matrix
         seg_end = K;
       }
@@ -796,7 +841,7 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
     K = min(HARD_ITER_FACTOR * K, cfg.max_iter);
     seg_end = K;
   }
-  if (opaque(tid0) == 0) { s.rho = rho; s.iters += K; s.hard |= hard; s.ratio = ratio; }
+  if (opaque(tid0) == 0) { s.rho = rho; s.iters += K; s.hard |= hard; }
   wsync<NW>();
 }
 
@@ -1085,7 +1130,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
 #else
     const bool first_qp = guard == 0;
 #endif
-    if (w_setup<TV, TIO, N, GAIT>(s, cfg, tabs, in, b, tid, first_qp)) {   // non-finite input -> zero outputs, status -1
+    if (w_setup<TV, TIO, N>(s, cfg, tabs, in, b, tid, first_qp)) {   // non-finite input -> zero outputs, status -1
       for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
       if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (size_t)(N + 1) * 13 + i] = (TIO)0;
       if (tid == 0) {
@@ -1101,18 +1146,23 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
     const int max_iter = cfg.max_iter, polish_max = cfg.polish_max;
     int ok = 0;
     const int warm = s.warm;
-    if (warm) {   // warm start: the guess's own active set first, no ADMM unless that fails
-      const int tries = warm == 1 ? WARM_POLISH : (warm == 2 ? 1 : 0);
-      for (int ps = 0; ps < polish_max && ps < tries && !ok; ++ps) ok = w_polish<TV, TP, N>(s, tabs, kinvP, tid);
-    }
-    for (int round = 0; !ok; ++round) {
-      w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, (round == 0 && warm >= 2) ? WARM_K : 0, tid);
-      const int budget = (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
+    // Round -1 exists only for a warm start: polish steps on the guess's own active set before any ADMM block.  (One loop,
+    // so that the polish and the ADMM block are each inlined exactly once: the kernel's code has to stay inside the
+    // instruction cache that the waves of two CUs share.)
+    const int warm_tries = warm == 1 ? WARM_POLISH : (warm == 2 ? 1 : 0);
+    for (int round = warm_tries > 0 ? -1 : 0; !ok; ++round) {
+      int budget = min(warm_tries, polish_max);
+      if (round >= 0) {
+        if (round > 0) {   // not solved: OSQP's rho adaptation from the residuals of the last ADMM iterate, then another block
+          const float ratio = w_ratio_lds<TV, N>(s, tabs, tid);
+          if (tid == 0 && isfinite(ratio) && (ratio > 2.f || ratio < 0.5f)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
+          wsync<NW>();
+        }
+        w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, (round == 0 && warm >= 2) ? WARM_K : 0, tid);
+        budget = (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
+      }
       for (int ps = 0; ps < budget && !ok; ++ps) ok = w_polish<TV, TP, N>(s, tabs, kinvP, tid);
-      if (ok || s.iters >= max_iter) break;
-      const float ratio = s.ratio;   // not solved: OSQP's rho adaptation from the residuals of the last ADMM iterate, then another block
-      if (tid == 0 && isfinite(ratio) && (ratio > 2.f || ratio < 0.5f)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
-      wsync<NW>();
+      if (ok || (round >= 0 && s.iters >= max_iter)) break;
     }
     w_output<TV, TIO, N>(s, tabs, ug, Xg, statusg, itersg, resg, in.y_state, b, ok, tid);
 #ifdef MPCQP_STAMPS
