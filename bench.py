@@ -160,13 +160,15 @@ def main():
     batch = mpcqp.synth.make_batch(B, N, delta, 20250809 + rank, gaits, mus)      # this rank's shard
     solver = mpcqp.MPCBatch(N=N, delta=delta, device=device_index, io_dtype="f32", precision=args.precision)
     dev = solver.upload(batch)
-    gathered = (torch.empty((world * B, 12), dtype=torch.float32, device=solver.device)
-                if args.allgather and world > 1 and backend == "nccl" else None)
+    gathered = None
+    if args.allgather and world > 1:   # RCCL: device buffers over xGMI; gloo (1-GPU rehearsals): through host memory
+        gathered = torch.empty((world * B, 12), dtype=torch.float32, device=solver.device if backend == "nccl" else "cpu")
 
     def step():
         out = solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], want_X=False)
         if gathered is not None:
-            dist.all_gather_into_tensor(gathered, out["u"][:, 0, :].contiguous())   # RCCL over xGMI
+            u0 = out["u"][:, 0, :].contiguous()
+            dist.all_gather_into_tensor(gathered, u0 if backend == "nccl" else u0.cpu())
         return out
 
     for _ in range(args.warmup):

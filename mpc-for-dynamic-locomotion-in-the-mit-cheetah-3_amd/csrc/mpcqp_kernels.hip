@@ -238,8 +238,9 @@ struct DeviceGuard {
 };
 
 bool wrench_path_applies(const mpcqp_engine* h) {
-  return h->wrench_ok && h->cfg.precision != MPCQP_PREC_F32 && (h->cfg.flags & MPCQP_FLAG_POLISH) &&
-         !(h->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL)) && h->cfg.alpha > 0.0;
+  return h->wrench_ok && h->cfg.precision != MPCQP_PREC_F32 &&
+         !(h->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL)) &&
+         (h->cfg.alpha > 0.0 || !(h->cfg.flags & MPCQP_FLAG_POLISH));   // (the polish system is D = 2 alpha + T'KT: needs alpha > 0)
 }
 
 bool fast_path_applies(const mpcqp_engine* h) {

@@ -60,7 +60,8 @@ struct SmemW {
     struct { TV rr[Geo::n]; TV xd[(N + 1) * 13]; };   // lever arms, x_des
   };
   union {   // ... and the free response (minus target) those of the ADMM iterate
-    struct { float ua[Geo::n], za[Geo::NL * 5], ya[Geo::NL * 5]; };   // last ADMM iterate (ya = multipliers, unscaled)
+    struct { TV ua[Geo::n], za[Geo::NL * 5], ya[Geo::NL * 5]; };   // last ADMM iterate (ya = multipliers, unscaled); TV so that an
+                                                                      // all-fp64 ADMM keeps its digits from block to block
     struct { TV e0P[Geo::NQ], e0Q[Geo::NQ]; };   // stage k = j + 1 at [6 j + q]: P = (Theta, p), Q = (Rz omega, v)
   };
   alignas(16) double E[N * 36];                          // T D^-1 T' blocks (TM-typed view)
@@ -68,6 +69,7 @@ struct SmemW {
   alignas(16) double bv[Geo::DP], cv[Geo::DP];           // mat-vec in / out (TM-typed view)
   float red[Geo::NW * 4];
   float kkt[4];
+  float resid[4];                // residuals of the last ADMM iterate that w_ratio looked at
   float gmax, rho, ratio;
   int iters, psteps, hard, warm, bad;
   uint8_t ct[Geo::NL];
@@ -553,8 +555,8 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
     s.gam[e] = (TV)2 * (s.wP[q] * d * d * aP + s.wQ[q] * d * aQ);
   }
   wsync<NW>();   // the free response has been consumed: its bytes become the ADMM iterate
-  for (int i = tid; i < n; i += NT) { s.uv[i] = 0; s.ua[i] = 0.f; s.pu[i] = 0; }
-  for (int i = tid; i < NL * 5; i += NT) { s.za[i] = 0.f; s.ya[i] = 0.f; s.py[i] = 0; }
+  for (int i = tid; i < n; i += NT) { s.uv[i] = 0; s.ua[i] = 0; s.pu[i] = 0; }
+  for (int i = tid; i < NL * 5; i += NT) { s.za[i] = 0; s.ya[i] = 0; s.py[i] = 0; }
   wsync<NW>();
   float q[1] = {0.f};
   if (tid < NL) {   // linear term g = T' gam (the gradient at u = 0)
@@ -614,7 +616,7 @@ __device__ __forceinline__ void w_warm_start(SmemW<TV, N>& s, const WrTabs& tabs
   wmax<2, NW>(amax, s.red, tid);
   wsync<NW>();
   if (!(amax[0] > 0.f)) {                                 // uniform: no guess
-    for (int i = tid; i < NL * 5; i += NT) s.ya[i] = 0.f;
+    for (int i = tid; i < NL * 5; i += NT) s.ya[i] = 0;
     for (int i = tid; i < n; i += NT) s.uv[i] = 0;
     wsync<NW>();
     return;
@@ -629,7 +631,7 @@ __device__ __forceinline__ void w_warm_start(SmemW<TV, N>& s, const WrTabs& tabs
     const TV mu = s.mu, flo = s.fmin, fhi = s.fmax;
     const TV fx = s.uv[3 * L], fy = s.uv[3 * L + 1], fz = s.uv[3 * L + 2];
     s.pu[3 * L] = fx; s.pu[3 * L + 1] = fy; s.pu[3 * L + 2] = fz;
-    s.ua[3 * L] = (float)fx; s.ua[3 * L + 1] = (float)fy; s.ua[3 * L + 2] = (float)fz;
+    s.ua[3 * L] = fx; s.ua[3 * L + 1] = fy; s.ua[3 * L + 2] = fz;
     const TV g[5] = {fz, fx - mu * fz, fx + mu * fz, fy - mu * fz, fy + mu * fz};
     const TV tb = (TV)1e-3 * fmax(fabs(fz), (TV)1), tf = (TV)1e-3 * fmax(mu * fabs(fz), (TV)1);
     TV y[5] = {0, 0, 0, 0, 0};
@@ -654,7 +656,7 @@ __device__ __forceinline__ void w_warm_start(SmemW<TV, N>& s, const WrTabs& tabs
       }
     }
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { s.py[5 * L + i] = y[i]; s.za[5 * L + i] = z[i]; if (!duals) s.ya[5 * L + i] = 0.f; }
+    for (int i = 0; i < 5; ++i) { s.py[5 * L + i] = y[i]; s.za[5 * L + i] = (TV)z[i]; if (!duals) s.ya[5 * L + i] = 0; }
   }
   wmax<1, NW>(rs, s.red, tid);
   if (tid == 0) s.warm = !duals ? 1 : (rs[0] <= WARM_KKT_TOL * fmaxf(s.gmax, 1.f) ? 2 : 3);
@@ -674,34 +676,35 @@ struct LegAdmm {
 // OSQP's rho-adaptation ratio sqrt((|r_prim| / norm_prim) / (|r_dual| / norm_dual)) of the ADMM iterate (u, z, y): one
 // structured gradient for H u + g, the rest per leg.  Uniform result.
 template <typename TV, int N>
-__device__ __forceinline__ float w_ratio(SmemW<TV, N>& s, const WrTabs& tabs, const float (&u)[3], const float (&z)[5], const float (&y)[5],
-                                         const float (&g)[3], const float mu, const bool leg, const int tid) {
+__device__ __forceinline__ float w_ratio(SmemW<TV, N>& s, const WrTabs& tabs, const TV (&u)[3], const TV (&z)[5], const TV (&y)[5],
+                                         const TV (&g)[3], const TV mu, const bool leg, const int tid) {
   constexpr int NL = WG<N>::NL, NW = WG<N>::NW;
   if (tid < NL) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) s.uv[3 * tid + a] = (TV)u[a];
+    for (int a = 0; a < 3; ++a) s.uv[3 * tid + a] = u[a];
   }
   wsync<NW>();
   TV hv[3];
   w_grad<TV, N>(s, tabs.K, tid, hv);
   float q[4] = {0.f, 0.f, 0.f, 0.f};
-  if (leg) {
-    const float m = mu * u[2];
-    const float gu[5] = {u[2], u[0] - m, u[0] + m, u[1] - m, u[1] + m};
+  if (leg) {   // (differences in TV: the ADMM-only termination test of an fp64 run looks below fp32 resolution)
+    const TV m = mu * u[2];
+    const TV gu[5] = {u[2], u[0] - m, u[0] + m, u[1] - m, u[1] + m};
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      q[0] = fmaxf(q[0], fabsf(gu[i] - z[i]));
-      q[2] = fmaxf(q[2], fmaxf(fabsf(gu[i]), fabsf(z[i])));
+      q[0] = fmaxf(q[0], fabsf((float)(gu[i] - z[i])));
+      q[2] = fmaxf(q[2], fmaxf(fabsf((float)gu[i]), fabsf((float)z[i])));
     }
-    const float Gy[3] = {y[1] + y[2], y[3] + y[4], y[0] + mu * (-y[1] + y[2] - y[3] + y[4])};
+    const TV Gy[3] = {y[1] + y[2], y[3] + y[4], y[0] + mu * (-y[1] + y[2] - y[3] + y[4])};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      q[1] = fmaxf(q[1], fabsf((float)hv[a] + Gy[a]));
-      q[3] = fmaxf(q[3], fmaxf(fabsf((float)hv[a] - g[a]), fabsf(Gy[a])));
+      q[1] = fmaxf(q[1], fabsf((float)(hv[a] + Gy[a])));
+      q[3] = fmaxf(q[3], fmaxf(fabsf((float)(hv[a] - g[a])), fabsf((float)Gy[a])));
     }
   }
   wmax<4, NW>(q, s.red, tid);
   const float sp = q[2], sd = fmaxf(q[3], s.gmax);
+  if (tid == 0) { s.resid[0] = q[0]; s.resid[1] = q[1]; s.resid[2] = sp; s.resid[3] = sd; }   // |r_prim|, |r_dual| and their norms (ADMM-only termination)
   return sqrtf((q[0] / fmaxf(sp, 1e-12f)) / fmaxf(q[1] / fmaxf(sd, 1e-12f), 1e-30f));
 }
 
@@ -710,12 +713,12 @@ template <typename TV, int N>
 __device__ __forceinline__ float w_ratio_lds(SmemW<TV, N>& s, const WrTabs& tabs, const int tid0) {
   constexpr int NL = WG<N>::NL;
   const int tid = opaque(tid0), L = min(tid, NL - 1);
-  float u[3], z[5], y[5], g[3];
+  TV u[3], z[5], y[5], g[3];
 #pragma unroll
-  for (int a = 0; a < 3; ++a) { u[a] = s.ua[3 * L + a]; g[a] = (float)s.gl[3 * L + a]; }
+  for (int a = 0; a < 3; ++a) { u[a] = s.ua[3 * L + a]; g[a] = s.gl[3 * L + a]; }
 #pragma unroll
   for (int i = 0; i < 5; ++i) { z[i] = s.za[5 * L + i]; y[i] = s.ya[5 * L + i]; }
-  return w_ratio<TV, N>(s, tabs, u, z, y, g, (float)s.mu, tid < NL, tid);
+  return w_ratio<TV, N>(s, tabs, u, z, y, g, s.mu, tid < NL, tid);
 }
 
 #ifndef MPCQP_W_ADAPT_AT
@@ -784,7 +787,7 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
 #pragma unroll
       for (int a = 0; a < 3; ++a) { A.u[a] = (TM)s.ua[3 * L + a]; A.g[a] = (TM)s.gl[3 * L + a]; }
 #pragma unroll
-      for (int i = 0; i < 5; ++i) { A.z[i] = (TM)s.za[5 * L + i]; A.yh[i] = (TM)(s.ya[5 * L + i] / rho); }
+      for (int i = 0; i < 5; ++i) { A.z[i] = (TM)s.za[5 * L + i]; A.yh[i] = (TM)(s.ya[5 * L + i] / (TV)rho); }
       A.lo0 = stance ? (TM)s.fmin : (TM)0; A.hi0 = stance ? (TM)s.fmax : (TM)0;
       A.loA = stance ? -BIG : (TM)0; A.hiB = stance ? BIG : (TM)0;
       bool rebuild = false;
@@ -817,11 +820,11 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
         STAMP(4);
         if (it >= K) break;
         {   // the single early rho check: OSQP's residual ratio after the first ADAPT_AT iterations
-          const float u3[3] = {(float)A.u[0], (float)A.u[1], (float)A.u[2]}, g3[3] = {(float)A.g[0], (float)A.g[1], (float)A.g[2]};
-          float z5[5], y5[5];
+          const TV u3[3] = {(TV)A.u[0], (TV)A.u[1], (TV)A.u[2]}, g3[3] = {(TV)A.g[0], (TV)A.g[1], (TV)A.g[2]};
+          TV z5[5], y5[5];
 #pragma unroll
-          for (int k = 0; k < 5; ++k) { z5[k] = (float)A.z[k]; y5[k] = rho * (float)A.yh[k]; }
-          ratio = w_ratio<TV, N>(s, tabs, u3, z5, y5, g3, (float)A.mu, leg, tid);
+          for (int k = 0; k < 5; ++k) { z5[k] = (TV)A.z[k]; y5[k] = (TV)rho * (TV)A.yh[k]; }
+          ratio = w_ratio<TV, N>(s, tabs, u3, z5, y5, g3, (TV)A.mu, leg, tid);
         }
         STAMP(5);
         if (ratio > ADAPT_THR) { rebuild = true; break; }        // uniform: slowly converging QP -> larger penalty, rebuilt matrix
@@ -829,9 +832,9 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
       }
       if (leg) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { s.ua[3 * L + a] = (float)A.u[a]; s.pu[3 * L + a] = (TV)A.u[a]; }
+        for (int a = 0; a < 3; ++a) { s.ua[3 * L + a] = (TV)A.u[a]; s.pu[3 * L + a] = (TV)A.u[a]; }
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { const float y = rho * (float)A.yh[k]; s.za[5 * L + k] = (float)A.z[k]; s.ya[5 * L + k] = y; s.py[5 * L + k] = (TV)y; }
+        for (int k = 0; k < 5; ++k) { const TV y = (TV)rho * (TV)A.yh[k]; s.za[5 * L + k] = (TV)A.z[k]; s.ya[5 * L + k] = y; s.py[5 * L + k] = y; }
       }
       wsync<NW>();
       if (!rebuild) break;
@@ -1034,7 +1037,7 @@ __device__ __forceinline__ void w_output(SmemW<TV, N>& s, const WrTabs& tabs, TI
     const bool stance = s.ct[L] != 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      TV v = ok ? s.uv[3 * L + c] : (TV)s.ua[3 * L + c];   // iteration cap: hand back the last ADMM iterate
+      TV v = ok == 1 ? s.uv[3 * L + c] : (TV)s.ua[3 * L + c];   // ADMM termination / iteration cap: the last ADMM iterate
       if (!stance) v = 0;
       s.uv[3 * L + c] = v;
     }
@@ -1042,7 +1045,7 @@ __device__ __forceinline__ void w_output(SmemW<TV, N>& s, const WrTabs& tabs, TI
   wsync<NW>();
   for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)s.uv[i];   // src/mpc.py:267-268
   if (y_state) {
-    for (int i = tid; i < NL * 5; i += NT) y_state[b * (NL * 5) + i] = ok ? (float)s.py[i] : s.ya[i];
+    for (int i = tid; i < NL * 5; i += NT) y_state[b * (NL * 5) + i] = (float)(ok == 1 ? s.py[i] : s.ya[i]);
   }
   if (Xg) {                                                          // src/mpc.py:265-266: roll the model forward (closed forms)
     TV g3[3];
@@ -1073,7 +1076,7 @@ __device__ __forceinline__ void w_output(SmemW<TV, N>& s, const WrTabs& tabs, TI
     }
   }
   if (tid == 0) {
-    statusg[b] = ok ? MPCQP_STATUS_SOLVED_POLISHED : MPCQP_STATUS_MAX_ITER;
+    statusg[b] = ok == 1 ? MPCQP_STATUS_SOLVED_POLISHED : (ok == 2 ? MPCQP_STATUS_SOLVED_ADMM : MPCQP_STATUS_MAX_ITER);
     itersg[b] = s.iters + 1000 * s.psteps;
     if (resg) { resg[2 * b] = s.kkt[1]; resg[2 * b + 1] = fmaxf(s.kkt[2], s.kkt[0]); }
   }
@@ -1149,17 +1152,28 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
     // Round -1 exists only for a warm start: polish steps on the guess's own active set before any ADMM block.  (One loop,
     // so that the polish and the ADMM block are each inlined exactly once: the kernel's code has to stay inside the
     // instruction cache that the waves of two CUs share.)
-    const int warm_tries = warm == 1 ? WARM_POLISH : (warm == 2 ? 1 : 0);
+    const int warm_tries = !(cfg.flags & MPCQP_FLAG_POLISH) ? 0 : (warm == 1 ? WARM_POLISH : (warm == 2 ? 1 : 0));
     for (int round = warm_tries > 0 ? -1 : 0; !ok; ++round) {
       int budget = min(warm_tries, polish_max);
       if (round >= 0) {
         if (round > 0) {   // not solved: OSQP's rho adaptation from the residuals of the last ADMM iterate, then another block
           const float ratio = w_ratio_lds<TV, N>(s, tabs, tid);
-          if (tid == 0 && isfinite(ratio) && (ratio > 2.f || ratio < 0.5f)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
+          // (tolerance 2 between ADMM + polish rounds; OSQP's own 5 when ADMM has to converge by itself: frequent changes of
+          //  the penalty stall the tail of a long ADMM run)
+          const float rtol = (cfg.flags & MPCQP_FLAG_POLISH) ? 2.f : 5.f;
+          if (tid == 0 && isfinite(ratio) && (ratio > rtol || ratio < 1.f / rtol)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
           wsync<NW>();
         }
         w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, (round == 0 && warm >= 2) ? WARM_K : 0, tid);
         budget = (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
+        if (!(cfg.flags & MPCQP_FLAG_POLISH)) {   // ADMM only (OSQP's own termination test, the reference leaves polish off, src/mpc.py:51-55)
+          (void)w_ratio_lds<TV, N>(s, tabs, tid);
+          wsync<NW>();
+          const float tp = (float)cfg.eps_abs + (float)cfg.eps_rel * s.resid[2], td = (float)cfg.eps_abs + (float)cfg.eps_rel * s.resid[3];
+          if (s.resid[0] <= tp && s.resid[1] <= td) ok = 2;
+          if (tid == 0) { s.kkt[0] = s.resid[1]; s.kkt[1] = s.resid[0]; s.kkt[2] = 0.f; }
+          budget = 0;
+        }
       }
       for (int ps = 0; ps < budget && !ok; ++ps) ok = w_polish<TV, TP, N>(s, tabs, kinvP, tid);
       if (ok || (round >= 0 && s.iters >= max_iter)) break;
