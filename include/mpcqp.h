@@ -169,6 +169,29 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
                            void* u_out, void* X_out, int32_t* status, int32_t* iters, float* res, void* stream);
 
 /*
+ * Closed-loop roll-out: B robots advance T control ticks on the device -- per tick the parameter fill of MPC.solve
+ * (src/mpc.py:176-254: x_des from the rolled-forward reference, contact masks / planned footholds from the robot's plan table,
+ * src/footstep_planner.py:226-246), the batched solve (warm-started from the previous tick when the engine has the warm-start
+ * flags), the "world step" x <- X[:,1] of the kinematic single-rigid-body stand-in (the model's own predicted next state; the
+ * reference steps a DART world here, src/main.py:130-188), and the reference roll-forward com_start += v d, yaw_start += w d
+ * (src/mpc.py:261-262).  3 launches per tick on `stream`, no host synchronisation and no host copies.
+ *   x        T  [B,13]     in: state at the first tick, out: state after T ticks
+ *   ref      T  [B,10]     in/out: roll0, pitch0, yaw_start, com_pos_start[3], v_com_ref[3], theta_dot (as mpcqp_solve_batch_gait)
+ *   plan_pos T  [B,S,4,3]  plan[step]['pos'] of all S steps (stance feet stand on the plan; swing feet carry no force)
+ *   plan_feet_id u8 [B,S,4]  plan[step]['feet_id']
+ *   plan_meta i32[B,4]     S_b (steps of this robot's plan, <= S), ss_duration, ds_duration, reserved (0)
+ *   tick     i32[B]        in/out: control tick of each robot (advanced by T)
+ *   mu       T  [B]
+ *   actual / desired / forces  T [B,T,12], each may be NULL: the log's TRACKING PERFORMANCE actual / desired rows and the
+ *                          stage-0 forces of every tick (src/mpc.py:295, src/main.py:216-218, src/logger.py:22-46)
+ *   solved   i32[B]        may be NULL: number of ticks whose QP was reported solved
+ * The oracle library exports the symbol and runs the same loop on host memory.
+ */
+int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* x, void* ref, const void* plan_pos,
+                  const uint8_t* plan_feet_id, const int32_t* plan_meta, int32_t* tick, const void* mu, void* actual,
+                  void* desired, void* forces, int32_t* solved, void* stream);
+
+/*
  * The step right after the solve in the reference's caller (ground_controller, src/main.py:205-214): joint torques of the
  * four legs from the stage-0 forces, tau_leg = J_leg^T (-f_leg).
  *   u    T [B,N,12]    as written by mpcqp_solve_batch (only stage 0 is read)

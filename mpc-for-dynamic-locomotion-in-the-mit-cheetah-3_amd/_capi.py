@@ -25,7 +25,7 @@ FLAG_POLISH, FLAG_WARM_START, FLAG_GENERAL_KERNEL, FLAG_NATURAL_ORDER, FLAG_WARM
 
 EXPORTED_SYMBOLS = (
     "mpcqp_version", "mpcqp_default_config", "mpcqp_create", "mpcqp_destroy", "mpcqp_solve_batch",
-    "mpcqp_solve_batch_gait", "mpcqp_torque_map", "mpcqp_last_kernel_ms", "mpcqp_last_error", "mpcqp_reserve",
+    "mpcqp_solve_batch_gait", "mpcqp_torque_map", "mpcqp_last_kernel_ms", "mpcqp_last_error", "mpcqp_reserve", "mpcqp_rollout",
 )
 
 
@@ -68,6 +68,8 @@ class Library:
         L.mpcqp_create.restype = c_int32
         L.mpcqp_destroy.argtypes = [c_void_p]
         L.mpcqp_reserve.argtypes = [c_void_p, c_int64]
+        L.mpcqp_rollout.argtypes = [c_void_p, c_int64, c_int32, c_int32] + [c_void_p] * 12
+        L.mpcqp_rollout.restype = ctypes.c_int
         L.mpcqp_reserve.restype = ctypes.c_int
         L.mpcqp_destroy.restype = c_int32
         L.mpcqp_solve_batch.argtypes = [c_void_p, c_int64] + [c_void_p] * 11
@@ -152,6 +154,25 @@ class Engine:
                                                      X_out or None, status, iters, res or None, stream or None)
         if rc != 0:
             raise MpcQpError(f"mpcqp_solve_batch_gait failed with code {rc}: {self.last_error()}")
+
+    def rollout_ptr(self, B, T, S, x, ref, plan_pos, plan_feet_id, plan_meta, tick, mu, actual, desired, forces, solved, stream=0):
+        """Raw call of the closed-loop roll-out (include/mpcqp.h, mpcqp_rollout); every argument is an integer address."""
+        rc = self.library.lib.mpcqp_rollout(self._h, int(B), int(T), int(S), x, ref, plan_pos, plan_feet_id, plan_meta, tick, mu,
+                                            actual or None, desired or None, forces or None, solved or None, stream or None)
+        if rc != 0:
+            raise MpcQpError(f"mpcqp_rollout failed with code {rc}: {self.last_error()}")
+
+    def rollout_host(self, x, ref, plan_pos, plan_feet_id, plan_meta, tick, mu, T):
+        """Oracle convenience (host memory, float64): returns the advanced (x, ref, tick) and the per-tick logs."""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64).copy()
+        x, ref, mu = f(x), f(ref), f(mu)
+        pos = f(plan_pos); fid = np.ascontiguousarray(plan_feet_id, dtype=np.uint8)
+        meta = np.ascontiguousarray(plan_meta, dtype=np.int32); tick = np.ascontiguousarray(tick, dtype=np.int32).copy()
+        B, S = pos.shape[0], pos.shape[1]
+        actual = np.zeros((B, T, 12)); desired = np.zeros((B, T, 12)); forces = np.zeros((B, T, 12)); solved = np.zeros(B, np.int32)
+        self.rollout_ptr(B, T, S, x.ctypes.data, ref.ctypes.data, pos.ctypes.data, fid.ctypes.data, meta.ctypes.data, tick.ctypes.data,
+                         mu.ctypes.data, actual.ctypes.data, desired.ctypes.data, forces.ctypes.data, solved.ctypes.data)
+        return {"x": x, "ref": ref, "tick": tick, "actual": actual, "desired": desired, "forces": forces, "solved": solved}
 
     def torque_map_ptr(self, B, u, jac, tau, stream=0):
         rc = self.library.lib.mpcqp_torque_map(self._h, int(B), u, jac, tau, stream or None)

@@ -82,6 +82,80 @@ mpcqp_gait_expand_kernel(const FastIn<TIO> in, const double d, const int N, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- closed-loop roll-out
+// mpcqp_rollout: B robots advance T control ticks on the device.  Per tick, per robot -- what
+// Lite3Controller.customPreStep / MPC.solve do on the host (src/main.py:130-188, src/mpc.py:176-271), with the DART world replaced
+// by the model's own predicted next state (the kinematic stand-in of the plumbing tests):
+//   expand   x_des from the rolled-forward reference (src/mpc.py:202-214, velocities zeroed on the last plan step, :178-183),
+//            contact masks and planned footholds from the robot's plan table (src/footstep_planner.py:226-246), lever arms
+//            (src/mpc.py:218-239; stance feet stand on the plan, swing feet carry no force)
+//   solve    the batched QP, warm-started from the previous tick when the engine was created with the warm-start flags
+//   advance  x <- X[:,1] (apply the first predicted step), com_start += v d, yaw_start += w d (src/mpc.py:261-262), tick += 1,
+//            log the tick's actual / desired state and stage-0 forces (the log's TRACKING PERFORMANCE / FORCES, src/logger.py:22-46)
+struct RolloutPlan { const void* pos; const uint8_t* feet_id; const int32_t* meta; };   // pos [B,S,4,3], feet_id [B,S,4], meta [B,4] = S, ss, ds, reserved
+
+template <typename TIO>
+__global__ void __launch_bounds__(256)
+mpcqp_rollout_expand_kernel(const TIO* __restrict__ x, const TIO* __restrict__ ref, const RolloutPlan plan, const int32_t* __restrict__ tick,
+                            const double d, const int N, const int Smax, const int64_t B, TIO* __restrict__ r, uint8_t* __restrict__ contact,
+                            TIO* __restrict__ xdes) {
+  const int nx = (N + 1) * 13, nr = N * 12, per = nx + nr;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * per) return;
+  const int64_t b = t / per;
+  const int e = (int)(t - b * per);
+  const TIO* rf = ref + b * 10;
+  const int S = plan.meta[b * 4 + 0], ss = plan.meta[b * 4 + 1], ds = plan.meta[b * 4 + 2], t0 = tick[b];
+  const int step0 = min(t0 / (ss + ds), S - 1);
+  const double gate = step0 == S - 1 ? 0.0 : 1.0;              // src/mpc.py:181-183: references zeroed on the last plan step
+  if (e < nx) {
+    const int k = e / 13, c = e % 13;
+    double v;
+    if (c < 2) v = (double)rf[c];
+    else if (c == 2) v = (double)rf[2] + (double)k * d * gate * (double)rf[9];
+    else if (c < 6) v = (double)rf[c] + (double)k * d * gate * (double)rf[6 + (c - 3)];
+    else if (c < 8) v = 0.0;
+    else if (c == 8) v = gate * (double)rf[9];
+    else if (c < 12) v = gate * (double)rf[6 + (c - 9)];
+    else v = (double)x[b * 13 + 12];
+    xdes[b * nx + e] = (TIO)v;
+  } else {
+    const int i = e - nx, k = i / 12, l = (i % 12) / 3, a = i % 3;
+    const int tau = t0 + k, si = min(tau / (ss + ds), S - 1), tin = tau - si * (ss + ds);   // past the plan: the last step, all stance
+    const TIO* pos = (const TIO*)plan.pos + ((b * Smax + si) * 4 + l) * 3;
+    const double com = k == 0 ? (double)x[b * 13 + 3 + a] : (double)rf[3 + a] + (double)k * d * gate * (double)rf[6 + a];
+    r[b * nr + i] = (TIO)((double)pos[a] - com);
+    if (a == 0) contact[b * (N * 4) + k * 4 + l] = (tin < ss) ? (plan.feet_id[(b * Smax + si) * 4 + l] ? 1 : 0) : 1;
+  }
+}
+
+template <typename TIO>
+__global__ void __launch_bounds__(256)
+mpcqp_rollout_advance_kernel(TIO* __restrict__ x, TIO* __restrict__ ref, const RolloutPlan plan, int32_t* __restrict__ tick, const TIO* __restrict__ X,
+                             const TIO* __restrict__ u, const int32_t* __restrict__ status, const double d, const int N, const int64_t B,
+                             const int T, const int it, TIO* __restrict__ actual, TIO* __restrict__ desired, TIO* __restrict__ forces,
+                             int32_t* __restrict__ solved) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  TIO* rf = ref + b * 10;
+  const int S = plan.meta[b * 4 + 0], ss = plan.meta[b * 4 + 1], ds = plan.meta[b * 4 + 2], t0 = tick[b];
+  const double gate = min(t0 / (ss + ds), S - 1) == S - 1 ? 0.0 : 1.0;
+  const size_t row = ((size_t)b * T + it) * 12;
+  if (actual) for (int c = 0; c < 12; ++c) actual[row + c] = x[b * 13 + c];                      // logger.log_tracking_data (src/mpc.py:295)
+  if (desired) {
+    const TIO des[12] = {rf[0], rf[1], rf[2], rf[3], rf[4], rf[5], (TIO)0, (TIO)0, (TIO)(gate * (double)rf[9]),
+                         (TIO)(gate * (double)rf[6]), (TIO)(gate * (double)rf[7]), (TIO)(gate * (double)rf[8])};
+    for (int c = 0; c < 12; ++c) desired[row + c] = des[c];
+  }
+  if (forces) for (int c = 0; c < 12; ++c) forces[row + c] = u[(size_t)b * N * 12 + c];          // src/main.py:216-218
+  const int st = status[b];
+  if (solved) solved[b] = (it == 0 ? 0 : solved[b]) + ((st == MPCQP_STATUS_SOLVED_POLISHED || st == MPCQP_STATUS_SOLVED_ADMM) ? 1 : 0);
+  for (int c = 0; c < 12; ++c) x[b * 13 + c] = X[((size_t)b * (N + 1) + 1) * 13 + c];          // the world step: the model's own prediction
+  for (int a = 0; a < 3; ++a) rf[3 + a] = (TIO)((double)rf[3 + a] + gate * (double)rf[6 + a] * d);   // src/mpc.py:261
+  rf[2] = (TIO)((double)rf[2] + gate * (double)rf[9] * d);                                      // src/mpc.py:262
+  tick[b] = t0 + 1;
+}
+
 }  // namespace
 
 // ======================================================================================================
@@ -99,6 +173,8 @@ struct mpcqp_engine {
   double* wr_K = nullptr;     // wrench-space engine (mpcqp_wrench.h): K_q [6][N][N], K^-1 in tile layout (fp32 / fp64)
   float* wr_kinv32 = nullptr;
   double* wr_kinv64 = nullptr;
+  void* roll_mem = nullptr;   // roll-out: u [B,N,12], X [B,N+1,13], status / iters [B] of the current tick
+  int64_t roll_cap = 0;
   void* gait_mem = nullptr;   // gait entry point: the expanded operator tuple [r | xdes | contact] of the current batch
   int64_t gait_cap = 0;
   bool wrench_ok = false;     // the configuration admits the wrench-space form (isotropic omega weight, positive velocity weights)
@@ -337,6 +413,7 @@ static void free_engine(mpcqp_engine* h) {
   if (h->order_mem) (void)hipFree(h->order_mem);
   if (h->dual_mem) (void)hipFree(h->dual_mem);
   if (h->gait_mem) (void)hipFree(h->gait_mem);
+  if (h->roll_mem) (void)hipFree(h->roll_mem);
   if (h->wr_K) (void)hipFree(h->wr_K);
   if (h->wr_kinv32) (void)hipFree(h->wr_kinv32);
   if (h->wr_kinv64) (void)hipFree(h->wr_kinv64);
@@ -541,6 +618,58 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "gait expansion kernel launch", he);
   h->ev0_set = true;   // the solve's timing starts in front of the expansion
   return mpcqp_solve_batch(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, stream);
+}
+
+int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* x, void* ref, const void* plan_pos, const uint8_t* plan_feet_id,
+                  const int32_t* plan_meta, int32_t* tick, const void* mu, void* actual, void* desired, void* forces, int32_t* solved,
+                  void* stream) {
+  if (!h) return MPCQP_EINVAL;
+  if (B < 0 || B > 0x7fffffff || T < 0 || S < 1) return fail(h, MPCQP_EINVAL, "mpcqp_rollout: size out of range");
+  if (B > 0 && (!x || !ref || !plan_pos || !plan_feet_id || !plan_meta || !tick || !mu)) return fail(h, MPCQP_EINVAL, "mpcqp_rollout: null buffer");
+  if (B == 0 || T == 0) return MPCQP_OK;
+  DeviceGuard guard(h->cfg.device);
+  if (guard.err != hipSuccess) return fail(h, MPCQP_EHIP, "hipSetDevice", guard.err);
+  const size_t el = h->cfg.dtype == MPCQP_DTYPE_F64 ? 8 : 4, N = (size_t)h->cfg.N;
+  if (reserve_gait(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_rollout: workspace allocation failed");
+  if (h->roll_cap < B) {
+    void* mem = nullptr;
+    if (hipMalloc(&mem, (size_t)B * ((N * 12 + (N + 1) * 13) * el + 8)) != hipSuccess) { (void)hipGetLastError(); return fail(h, MPCQP_ENOMEM, "mpcqp_rollout: workspace allocation failed"); }
+    if (h->roll_mem) { (void)hipDeviceSynchronize(); (void)hipFree(h->roll_mem); }
+    (void)hipMemset(mem, 0, (size_t)B * ((N * 12 + (N + 1) * 13) * el + 8));   // zeros = "no guess" for a warm-started engine
+    h->roll_mem = mem; h->roll_cap = B;
+  }
+  char* gb = (char*)h->gait_mem;
+  void* r = gb;
+  void* xdes = gb + (size_t)B * N * 12 * el;
+  uint8_t* contact = (uint8_t*)(gb + (size_t)B * (N * 12 + (N + 1) * 13) * el);
+  char* rb = (char*)h->roll_mem;
+  void* u = rb;
+  void* X = rb + (size_t)B * N * 12 * el;
+  int32_t* status = (int32_t*)(rb + (size_t)B * (N * 12 + (N + 1) * 13) * el);
+  int32_t* iters = status + B;
+  const RolloutPlan plan = {plan_pos, plan_feet_id, plan_meta};
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = B * (int64_t)(N * 12 + (N + 1) * 13);
+  const dim3 ge((unsigned)((total + 255) / 256)), ga((unsigned)((B + 255) / 256));
+  for (int it = 0; it < T; ++it) {   // 3 launches per tick on the caller's stream, no host synchronisation and no copies in between
+    if (el == 8)
+      hipLaunchKernelGGL((mpcqp_rollout_expand_kernel<double>), ge, dim3(256), 0, st, (const double*)x, (const double*)ref, plan, tick, h->cfg.delta,
+                         (int)N, (int)S, B, (double*)r, contact, (double*)xdes);
+    else
+      hipLaunchKernelGGL((mpcqp_rollout_expand_kernel<float>), ge, dim3(256), 0, st, (const float*)x, (const float*)ref, plan, tick, h->cfg.delta,
+                         (int)N, (int)S, B, (float*)r, contact, (float*)xdes);
+    const int rc = mpcqp_solve_batch(h, B, x, r, contact, xdes, mu, u, X, status, iters, nullptr, stream);
+    if (rc != MPCQP_OK) return rc;
+    if (el == 8)
+      hipLaunchKernelGGL((mpcqp_rollout_advance_kernel<double>), ga, dim3(256), 0, st, (double*)x, (double*)ref, plan, tick, (const double*)X,
+                         (const double*)u, status, h->cfg.delta, (int)N, B, (int)T, it, (double*)actual, (double*)desired, (double*)forces, solved);
+    else
+      hipLaunchKernelGGL((mpcqp_rollout_advance_kernel<float>), ga, dim3(256), 0, st, (float*)x, (float*)ref, plan, tick, (const float*)X,
+                         (const float*)u, status, h->cfg.delta, (int)N, B, (int)T, it, (float*)actual, (float*)desired, (float*)forces, solved);
+    const hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return fail(h, MPCQP_EHIP, "roll-out kernel launch", he);
+  }
+  return MPCQP_OK;
 }
 
 int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* u, const void* jac, void* tau, void* stream) {

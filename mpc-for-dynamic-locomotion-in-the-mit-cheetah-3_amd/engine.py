@@ -123,6 +123,26 @@ class MPCBatch:
                                          out["iters"].data_ptr(), out["res"].data_ptr(), st.cuda_stream)
         return out
 
+    def rollout(self, x, ref, plan_pos, plan_feet_id, plan_meta, tick, mu, T, log=True, stream=None):
+        """Closed-loop roll-out of B robots over T control ticks on the device (include/mpcqp.h, mpcqp_rollout): `x`, `ref` and `tick`
+        are advanced IN PLACE; returns the per-tick logs (the reference log's TRACKING PERFORMANCE actual / desired rows and stage-0
+        FORCES, src/logger.py:22-46) and the per-robot count of solved ticks."""
+        torch = _torch()
+        B, S = int(plan_pos.shape[0]), int(plan_pos.shape[1])
+        for t, shape, dt in ((x, (B, 13), self.tdtype), (ref, (B, 10), self.tdtype), (plan_pos, (B, S, 4, 3), self.tdtype),
+                             (plan_feet_id, (B, S, 4), torch.uint8), (plan_meta, (B, 4), torch.int32), (tick, (B,), torch.int32),
+                             (mu, (B,), self.tdtype)):
+            if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError(f"operand mismatch: expected {shape} {dt} contiguous on {self.device}, got {tuple(t.shape)} {t.dtype} on {t.device}")
+        mk = lambda: torch.empty((B, T, 12), dtype=self.tdtype, device=self.device) if log else None
+        actual, desired, forces = mk(), mk(), mk()
+        solved = torch.zeros(B, dtype=torch.int32, device=self.device)
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        p = lambda t: t.data_ptr() if t is not None else None
+        self.engine.rollout_ptr(B, T, S, x.data_ptr(), ref.data_ptr(), plan_pos.data_ptr(), plan_feet_id.data_ptr(), plan_meta.data_ptr(),
+                                tick.data_ptr(), mu.data_ptr(), p(actual), p(desired), p(forces), solved.data_ptr(), st.cuda_stream)
+        return {"actual": actual, "desired": desired, "forces": forces, "solved": solved}
+
     def torque_map(self, u, jac, stream=None):
         """tau[B,4,3] = J^T (-f) of the stage-0 forces (src/main.py:212-214); jac[B,4,3,3] world-frame leg Jacobians."""
         torch = _torch()

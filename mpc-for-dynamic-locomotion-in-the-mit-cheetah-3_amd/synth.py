@@ -171,3 +171,33 @@ def expand_gait_batch(g, N=10, delta=0.03):
     r[:, 0] = np.asarray(g["feet0"], float) - x0[:, None, 3:6]
     return {"x0": x0, "r": r, "contact": contact, "xdes": xdes, "mu": np.asarray(g["mu"], float)}
 
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Closed-loop roll-out batches (include/mpcqp.h, mpcqp_rollout): per-robot plan tables from the footstep planner
+# ----------------------------------------------------------------------------------------------------------------------
+def make_rollout_batch(B, N=10, delta=0.03, seed=20250813, gait_names=("trot", "gallop", "amble"), mus=(0.5, 0.7, 1.0), ss=4, ds=2,
+                       total_steps=50, v_ref=(0.18, 0.0, 0.0)):
+    """B robots at the start of a walk: state, reference descriptor, plan table (host planner, one plan per robot), gait clock.
+    BASELINE config-1 timing by default (the reference's step durations in seconds: 4 / 2 ticks of 0.03 s).  Heading 0 for every
+    robot: the reference integrates v_com_ref in world axes (src/mpc.py:202-214) while its planner walks along the heading."""
+    from .footstep_planner import LEGS, FootstepPlanner
+    rng = np.random.default_rng(seed)
+    x = np.zeros((B, 13)); ref = np.zeros((B, 10))
+    pos = np.zeros((B, total_steps, 4, 3)); fid = np.ones((B, total_steps, 4), np.uint8); meta = np.zeros((B, 4), np.int32)
+    gid = rng.integers(0, len(gait_names), B)
+    mu = np.asarray(mus, float)[rng.integers(0, len(mus), B)]
+    for b in range(B):
+        com = np.array([0.0, 0.0, H_COM]) + rng.normal(0.0, 0.005, 3) * np.array([1.0, 1.0, 0.5])
+        feet = NOMINAL_FEET + np.array([com[0], com[1], H_COM]) + np.concatenate([rng.normal(0.0, 0.003, (4, 2)), np.zeros((4, 1))], axis=1)
+        params = {"g": G_ACC, "h": H_COM, "step_height": 0.08, "ss_duration": ss, "ds_duration": ds, "world_time_step": delta,
+                  "total_steps": total_steps, "first_swing": np.array(GAITS[gait_names[gid[b]]]), "µ": float(mu[b]), "N": N, "dof": 18,
+                  "v_com_ref": np.asarray(v_ref, float), "theta_dot": 0.0, "log_samples": 0}
+        initial = {l: feet[k].copy() for k, l in enumerate(LEGS)}
+        initial.update(roll=0.0, pitch=0.0, yaw=0.0, com_position=com.copy())
+        pl = FootstepPlanner(initial, params, show=False)
+        pos[b] = pl.pos[:total_steps]; fid[b] = pl.feet_id[:total_steps]; meta[b] = (total_steps, ss, ds, 0)
+        x[b, 3:6] = com; x[b, 6:9] = rng.normal(0.0, 0.02, 3); x[b, 9:12] = rng.normal(0.0, 0.02, 3); x[b, 12] = G_ACC
+        ref[b] = [0.0, 0.0, 0.0, com[0], com[1], H_COM, v_ref[0], v_ref[1], v_ref[2], 0.0]
+    return {"x": x, "ref": ref, "plan_pos": pos, "plan_feet_id": fid, "plan_meta": meta, "tick": np.zeros(B, np.int32), "mu": mu,
+            "gait_ids": gid}

@@ -678,6 +678,77 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0v, const voi
   return rc;
 }
 
+/* Closed-loop roll-out on host memory, fp64: the literal per-tick loop of Lite3Controller.customPreStep / MPC.solve
+ * (src/main.py:130-188, src/mpc.py:176-271) with the world step replaced by the model's predicted next state X[:,1].
+ * Checker for the product library's device roll-out (same argument layout, include/mpcqp.h). */
+int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* xv, void* refv, const void* plan_posv, const uint8_t* plan_feet_id,
+                  const int32_t* plan_meta, int32_t* tick, const void* muv, void* actualv, void* desiredv, void* forcesv, int32_t* solved,
+                  void* stream) {
+  if (!h) return MPCQP_EINVAL;
+  if (B < 0 || T < 0 || S < 1 || (B > 0 && (!xv || !refv || !plan_posv || !plan_feet_id || !plan_meta || !tick || !muv))) return MPCQP_EINVAL;
+  if (B == 0 || T == 0) return MPCQP_OK;
+  const int N = h->cfg.N;
+  const double d = h->cfg.delta;
+  double *x = (double*)xv, *ref = (double*)refv, *actual = (double*)actualv, *desired = (double*)desiredv, *forces = (double*)forcesv;
+  const double* pos = (const double*)plan_posv;
+  double* r = (double*)malloc(sizeof(double) * (size_t)B * N * 12);
+  double* xd = (double*)malloc(sizeof(double) * (size_t)B * (N + 1) * NX);
+  double* u = (double*)malloc(sizeof(double) * (size_t)B * N * 12);
+  double* X = (double*)malloc(sizeof(double) * (size_t)B * (N + 1) * NX);
+  uint8_t* ct = (uint8_t*)malloc((size_t)B * N * 4);
+  int32_t* st = (int32_t*)malloc(sizeof(int32_t) * (size_t)B * 2);
+  int rc = (r && xd && u && X && ct && st) ? MPCQP_OK : MPCQP_ENOMEM;
+  for (int it = 0; it < T && rc == MPCQP_OK; it++) {
+    for (int64_t b = 0; b < B; b++) {
+      const double* rf = ref + b * 10;
+      const int Sb = plan_meta[b * 4], ss = plan_meta[b * 4 + 1], ds = plan_meta[b * 4 + 2], t0 = tick[b];
+      int step0 = t0 / (ss + ds); if (step0 > Sb - 1) step0 = Sb - 1;
+      const double gate = step0 == Sb - 1 ? 0.0 : 1.0;                                        /* src/mpc.py:181-183 */
+      for (int k = 0; k <= N; k++) {                                                           /* src/mpc.py:202-214 */
+        double* xk = xd + (b * (N + 1) + k) * NX;
+        memset(xk, 0, sizeof(double) * NX);
+        xk[0] = rf[0]; xk[1] = rf[1];
+        xk[2] = rf[2] + k * d * gate * rf[9];
+        for (int a = 0; a < 3; a++) { xk[3 + a] = rf[3 + a] + k * d * gate * rf[6 + a]; xk[9 + a] = gate * rf[6 + a]; }
+        xk[8] = gate * rf[9];
+        xk[12] = x[b * NX + 12];
+      }
+      for (int k = 0; k < N; k++) {
+        const int tau = t0 + k;
+        int si = tau / (ss + ds); if (si > Sb - 1) si = Sb - 1;
+        const int tin = tau - si * (ss + ds);
+        for (int l = 0; l < 4; l++) {
+          ct[(b * N + k) * 4 + l] = (tin < ss) ? (plan_feet_id[(b * S + si) * 4 + l] ? 1 : 0) : 1;   /* footstep_planner.py:239-246 */
+          for (int a = 0; a < 3; a++)                                                          /* src/mpc.py:218-239 */
+            r[((b * N + k) * 4 + l) * 3 + a] = pos[((b * S + si) * 4 + l) * 3 + a] - (k == 0 ? x[b * NX + 3 + a] : xd[(b * (N + 1) + k) * NX + 3 + a]);
+        }
+      }
+    }
+    rc = mpcqp_solve_batch(h, B, x, r, ct, xd, muv, u, X, st, st + B, NULL, stream);
+    if (rc != MPCQP_OK) break;
+    for (int64_t b = 0; b < B; b++) {
+      double* rf = ref + b * 10;
+      const int Sb = plan_meta[b * 4], ss = plan_meta[b * 4 + 1], ds = plan_meta[b * 4 + 2], t0 = tick[b];
+      int step0 = t0 / (ss + ds); if (step0 > Sb - 1) step0 = Sb - 1;
+      const double gate = step0 == Sb - 1 ? 0.0 : 1.0;
+      const size_t row = ((size_t)b * T + it) * 12;
+      if (actual) for (int c = 0; c < 12; c++) actual[row + c] = x[b * NX + c];               /* src/mpc.py:295 */
+      if (desired) {
+        const double des[12] = {rf[0], rf[1], rf[2], rf[3], rf[4], rf[5], 0, 0, gate * rf[9], gate * rf[6], gate * rf[7], gate * rf[8]};
+        for (int c = 0; c < 12; c++) desired[row + c] = des[c];
+      }
+      if (forces) for (int c = 0; c < 12; c++) forces[row + c] = u[(size_t)b * N * 12 + c];   /* src/main.py:216-218 */
+      if (solved) solved[b] = (it == 0 ? 0 : solved[b]) + ((st[b] == MPCQP_STATUS_SOLVED_POLISHED || st[b] == MPCQP_STATUS_SOLVED_ADMM) ? 1 : 0);
+      for (int c = 0; c < 12; c++) x[b * NX + c] = X[(b * (N + 1) + 1) * NX + c];
+      for (int a = 0; a < 3; a++) rf[3 + a] += gate * rf[6 + a] * d;                          /* src/mpc.py:261 */
+      rf[2] += gate * rf[9] * d;                                                              /* src/mpc.py:262 */
+      tick[b] = t0 + 1;
+    }
+  }
+  free(r); free(xd); free(u); free(X); free(ct); free(st);
+  return rc;
+}
+
 /* src/main.py:212-214: tau[leg] = J[leg].T @ -forces[leg]; stage-0 forces only. */
 int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* uv, const void* jacv, void* tauv, void* stream) {
   (void)stream;
