@@ -71,3 +71,48 @@ def test_config1_closed_loop_plumbing(oracle_lib):
         ctl.logger.save_log(f)
         back = ctl.logger.load_log(f)
         assert back["FORCES/FL_FOOT/z"].shape == (T,) and "MPC PREDICTIONS/1/predicted_state" in back
+
+
+def test_log_file_in_the_reference_format(oracle_lib, tmp_path):
+    """the run log is written as the reference writes it (src/logger.py:64-66: pickle of the nested
+    dict) so that `Logger.load_log` / plot.py-style consumers (src/logger.py:69-72, src/plot.py:12-83) read it unchanged.  The
+    schema is compared key by key with the reference's own committed log (tests/golden/ref_log.npz holds its arrays)."""
+    import pickle
+    ctl = Lite3Controller(OracleMPC)
+    T = 81
+    for _ in range(T):
+        ctl.customPreStep()
+    f = str(tmp_path / "simulation_log.pkl")
+    ctl.logger.save_log(f)
+    with open(f, "rb") as fh:
+        raw = pickle.load(fh)                                        # what the reference's load_log does (our own file)
+    assert set(raw) == {"mpc_freq", "sim_params", "total_sim_steps", "time array", "FEET POS", "MPC PREDICTIONS", "TRACKING PERFORMANCE",
+                        "FORCES", "CONTROL EFFORT"}                 # src/logger.py:22-46
+    legs = ["FL_FOOT", "FR_FOOT", "HL_FOOT", "HR_FOOT"]
+    assert list(raw["FEET POS"]) == legs and list(raw["FORCES"]) == legs and list(raw["CONTROL EFFORT"]) == legs
+    assert list(raw["FORCES"]["FL_FOOT"]) == ["x", "y", "z"] and list(raw["CONTROL EFFORT"]["HR_FOOT"]) == ["HR_HipX", "HR_HipY", "HR_Knee"]
+    assert len(raw["time array"]) == T and len(raw["TRACKING PERFORMANCE"]["actual"]) == T and len(raw["FORCES"]["HL_FOOT"]["z"]) == T
+    assert len(raw["TRACKING PERFORMANCE"]["actual"][0]) == 12 and np.asarray(raw["TRACKING PERFORMANCE"]["desired"][0]).shape == (12,)
+    assert [p["time step"] for p in raw["MPC PREDICTIONS"]] == [0, 80]
+    p0 = raw["MPC PREDICTIONS"][0]
+    assert set(p0) == {"time step", "predicted_state", "desired_state", "predicted forces"}
+    assert p0["predicted_state"].shape == (12, 11) and p0["desired_state"].shape == (12, 11) and p0["predicted forces"].shape == (4, 10)
+    assert raw["sim_params"]["N"] == 10 and raw["sim_params"]["µ"] == 1
+    # a plot.py-style consumer: load through the Logger and slice the way src/plot.py / src/utils.py:131-209 do
+    from mpcqp.logger import Logger
+    lg = Logger({"params": {}, "total_sim_steps": 0})
+    log = lg.load_log(f)
+    z = np.array(log["TRACKING PERFORMANCE"]["actual"])[:, 5]
+    fz = np.array([log["FORCES"][l]["z"] for l in legs])
+    assert z.shape == (T,) and fz.shape == (4, T) and abs(z.mean() - 0.285) < 0.01
+    # the restricted loader refuses anything but arrays
+    bad = str(tmp_path / "bad.pkl")
+    with open(bad, "wb") as fh:
+        pickle.dump({"x": np.linalg.norm}, fh)
+    import pytest
+    with pytest.raises(pickle.UnpicklingError):
+        lg.load_log(bad)
+    # one robot of a device roll-out in the same layout
+    act, des, frc = np.zeros((5, 12)), np.ones((5, 12)), np.arange(60.0).reshape(5, 12)
+    lr = Logger.from_rollout({"N": 10}, act, des, frc)
+    assert lr.log["FORCES"]["FR_FOOT"]["z"] == [5.0, 17.0, 29.0, 41.0, 53.0] and len(lr.log["TRACKING PERFORMANCE"]["actual"]) == 5
