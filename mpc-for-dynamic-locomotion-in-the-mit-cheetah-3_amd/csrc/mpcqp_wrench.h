@@ -721,6 +721,10 @@ __device__ __forceinline__ float w_ratio_lds(SmemW<TV, N>& s, const WrTabs& tabs
   return w_ratio<TV, N>(s, tabs, u, z, y, g, s.mu, tid < NL, tid);
 }
 
+#ifndef MPCQP_W_POLISH_PATIENCE
+#define MPCQP_W_POLISH_PATIENCE 1
+#endif
+constexpr int POLISH_PATIENCE = MPCQP_W_POLISH_PATIENCE;   // polish steps that may fail to halve the KKT violation before the round gives up
 #ifndef MPCQP_W_ADAPT_AT
 #define MPCQP_W_ADAPT_AT 25
 #endif
@@ -1175,7 +1179,16 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
           budget = 0;
         }
       }
-      for (int ps = 0; ps < budget && !ok; ++ps) ok = w_polish<TV, TP, N>(s, tabs, kinvP, tid);
+      // Active-set steps while they make progress: a step that does not at least halve the KKT violation of the previous one
+      // (primal + dual-sign, each relative to its scale) means ADMM has not settled the active set yet -- back to ADMM rather
+      // than through the rest of the budget (each step costs an fp64 sweep, about 50 ADMM iterations).
+      float vprev = INFINITY;
+      for (int ps = 0; ps < budget && !ok; ++ps) {
+        ok = w_polish<TV, TP, N>(s, tabs, kinvP, tid);
+        const float v = s.kkt[1] + s.kkt[2] / fmaxf(s.gmax, 1.f) * 100.f;
+        if (!ok && ps >= POLISH_PATIENCE && !(v < 0.5f * vprev) && (round < 0 || s.iters < max_iter)) break;   // uniform (the last round keeps its full budget)
+        vprev = v;
+      }
       if (ok || (round >= 0 && s.iters >= max_iter)) break;
     }
     w_output<TV, TIO, N>(s, tabs, ug, Xg, statusg, itersg, resg, in.y_state, b, ok, tid);

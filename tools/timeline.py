@@ -7,7 +7,7 @@ import mpcqp
 from mpcqp import _capi
 lib = _capi.Library(os.path.join(REPO, "mpc-for-dynamic-locomotion-in-the-mit-cheetah-3_amd", "csrc", "libmpcqp_stamps.so"))
 _capi._product = lib
-B = 4096
+B = int(os.environ.get("TL_B", "4096"))
 flags = 1 | (8 if len(sys.argv) > 1 and sys.argv[1] == "natural" else 0)
 batch = mpcqp.synth.config3(B)
 sol = mpcqp.MPCBatch(N=10, precision="mixed", flags=flags)
