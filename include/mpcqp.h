@@ -65,8 +65,8 @@ extern "C" {
                                     active set and falls back to an ADMM block started from the guess.  The engine also keeps,
                                     per batch slot, the multipliers of its previous solve and starts from those when it has
                                     them (slot b of consecutive calls = the same robot).  Same optimum, same
-                                    status / tolerance contract as a cold solve.  Fast path only (N = 10, MIXED / F32,
-                                    polish on); the general kernel and the CPU checker accept the flag and start cold. */
+                                    status / tolerance contract as a cold solve.  Horizon 10 with polish on; horizon 20 and
+                                    the CPU checker accept the flag (horizon 20 uses the guess, the checker starts cold). */
 #define MPCQP_FLAG_WARM_SHIFT 16u    /* with WARM_START: the guess is the PREVIOUS control tick's solution, left in u_out unshifted as the
                                         reference leaves it; the engine uses its stage k + 1 for stage k (last stage repeated) */
 #define MPCQP_FLAG_GENERAL_KERNEL 4u /* product library: use the single-launch general kernel even where the fast path applies */
@@ -83,7 +83,7 @@ extern "C" {
  */
 typedef struct MpcQpConfig {
   uint32_t size;        /* sizeof(MpcQpConfig) */
-  int32_t N;            /* horizon, params['N'] (src/mpc.py:30); engine supports 10 and 20 */
+  int32_t N;            /* horizon, params['N'] (src/mpc.py:30); engine supports 10 and 20 (all precisions at both) */
   double delta;         /* params['world_time_step'] (src/mpc.py:31) */
   double m;             /* 8.885 (src/mpc.py:71) */
   double Ibody_inv[3];  /* diag(1/0.24, 1, 1) (src/mpc.py:73-76) */
@@ -161,8 +161,9 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
  *   gait      i32[B,4]      ticks elapsed in the current step, ss_duration, ds_duration, reserved (0)
  *   feet_id   u8 [B,2,4]    plan[step]['feet_id'] of the current and of the next step (1 = stance during single support)
  * Stage k uses step 0 while t_in_step + k < ss + ds, else step 1; N must not exceed ss + ds so that the horizon spans at
- * most two steps.  Outputs as mpcqp_solve_batch.  Product library: fast path only (N = 10, MIXED/F32, polish, alpha > 0);
- * otherwise MPCQP_EINVAL.  The oracle library does not export this entry (tests expand the descriptors on the host).
+ * most two steps (mpcqp_rollout takes whole plan tables and has no such limit).  The descriptors are expanded by an
+ * element-wise pre-pass into an engine-owned tuple workspace, then solved exactly as mpcqp_solve_batch would.  Outputs as
+ * mpcqp_solve_batch.  Product library: horizon 10; otherwise MPCQP_EINVAL.
  */
 int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void* ref, const void* feet0,
                            const void* footholds, const int32_t* gait, const uint8_t* feet_id, const void* mu,

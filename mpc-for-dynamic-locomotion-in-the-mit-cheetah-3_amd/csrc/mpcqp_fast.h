@@ -105,8 +105,8 @@ typedef f2 Tile[6][8];
 __device__ __forceinline__ f2 mk2(float a, float b) { f2 t = {a, b}; return t; }   // NB: (f2)(a, b) would be a cast of a comma expression
 __device__ __forceinline__ f2 splat2(float v) { return mk2(v, v); }
 
-// Inputs of one solve: either the expanded operator tuple (x0, r, contact, xdes, mu) or, for the gait entry point, compact
-// descriptors that are expanded into the same LDS arrays on the device.
+// Inputs of one solve: the operator tuple (x0, r, contact, xdes, mu).  The descriptor fields belong to the gait entry point,
+// whose expansion kernel (mpcqp_kernels.hip) turns them into a tuple in the engine's workspace before the solve.
 template <typename TIO>
 struct FastIn {
   const TIO* x0; const TIO* r; const uint8_t* contact; const TIO* xdes; const TIO* mu;             // tuple form
@@ -125,49 +125,6 @@ __device__ __forceinline__ int fast_load_tuple(SmemF<TV>& s, const FastIn<TIO>& 
   for (int i = tid; i < (N + 1) * 13; i += NT) { const TV v = (TV)in.xdes[b * (N + 1) * 13 + i]; s.xd[i] = v; bad |= !isfinite(v); }
   for (int i = tid; i < N * 12; i += NT) { const TV v = (TV)in.r[b * N * 12 + i]; s.rr[i] = v; bad |= !isfinite(v); }
   for (int i = tid; i < N * 4; i += NT) s.ct[i] = in.contact[b * N * 4 + i] ? 1 : 0;
-  if (tid == 0) { const TV m = (TV)in.mu[b]; s.mu = m; bad |= !isfinite(m); }
-  return bad;
-}
-
-// Gait form: what MPC.solve computes on the host every tick (src/mpc.py:178-254) from the planner queries
-// (src/footstep_planner.py:226-246), done here per QP:
-//   x_des[k]   = [roll0, pitch0, yaw_start + k d w, com_start + k d v, 0, 0, w, v, g]             (src/mpc.py:202-214)
-//   contact[k] = feet_id[step(k)] during that step's first ss ticks, else all stance          (footstep_planner.py:239-246)
-//   r[0]       = measured foot - measured com;  r[k>=1] = planned foothold of step(k) - x_des com(k)   (src/mpc.py:218-239)
-// with step(k) = 0 while t_in_step + k < ss + ds, else 1 (the horizon spans at most two steps; past the second step's
-// end everything is stance, like the clamped end of the plan).  ref = [roll0, pitch0, yaw_start, com_start(3), v(3), w].
-template <typename TV, typename TIO>
-__device__ __forceinline__ int fast_load_gait(SmemF<TV>& s, const FastIn<TIO>& in, const DevCfg& cfg, size_t b, int tid) {
-  constexpr int N = FG::N, NT = FG::NT;
-  int bad = 0;
-  const TV d = (TV)cfg.delta;
-  const int tis = in.gait[b * 4 + 0], ss = in.gait[b * 4 + 1], ds = in.gait[b * 4 + 2];
-  const TIO* ref = in.ref + b * 10;
-  for (int i = tid; i < 13; i += NT) { const TV v = (TV)in.x0[b * 13 + i]; s.x0[i] = v; bad |= !isfinite(v); }
-  for (int i = tid; i < (N + 1) * 13; i += NT) {
-    const int k = i / 13, c = i % 13;
-    TV v;
-    if (c < 2) v = (TV)ref[c];
-    else if (c == 2) v = (TV)ref[2] + (TV)k * d * (TV)ref[9];
-    else if (c < 6) v = (TV)ref[c] + (TV)k * d * (TV)ref[6 + (c - 3)];
-    else if (c < 8) v = (TV)0;
-    else if (c == 8) v = (TV)ref[9];
-    else if (c < 12) v = (TV)ref[6 + (c - 9)];
-    else v = (TV)in.x0[b * 13 + 12];
-    s.xd[i] = v;
-    bad |= !isfinite(v);
-  }
-  for (int i = tid; i < N * 12; i += NT) {
-    const int k = i / 12, l = (i % 12) / 3, a = i % 3;
-    int tau = tis + k, st = 0;
-    if (tau >= ss + ds) { tau -= ss + ds; st = 1; }
-    TV v;
-    if (k == 0) v = (TV)in.feet0[b * 12 + l * 3 + a] - (TV)in.x0[b * 13 + 3 + a];
-    else v = (TV)in.footholds[b * 24 + st * 12 + l * 3 + a] - ((TV)ref[3 + a] + (TV)k * d * (TV)ref[6 + a]);
-    s.rr[i] = v;
-    bad |= !isfinite(v);
-    if (a == 0) s.ct[k * 4 + l] = (tau < ss) ? (in.feet_id[b * 8 + st * 4 + l] ? 1 : 0) : 1;
-  }
   if (tid == 0) { const TV m = (TV)in.mu[b]; s.mu = m; bad |= !isfinite(m); }
   return bad;
 }
@@ -630,13 +587,13 @@ __device__ __forceinline__ void fast_warm_start(SmemF<TV>& s, const TIO* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------ phases
-template <typename TV, typename TIO, bool GAIT>
+template <typename TV, typename TIO>
 MPCQP_PHASE int ph_setup(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const FastIn<TIO> in, size_t b,
                          const int first) {
   SmemF<TV>& s = lds<TV>();
   const int tid = threadIdx.x;
   STAMP_INIT
-  const int bad = GAIT ? fast_load_gait<TV, TIO>(s, in, *cfgp, b, tid) : fast_load_tuple<TV, TIO>(s, in, b, tid);
+  const int bad = fast_load_tuple<TV, TIO>(s, in, b, tid);
   STAMP(13);
   if (fast_setup<TV>(s, *cfgp, ctab, bad, tid, first != 0)) return 1;
   STAMP(14);
@@ -942,7 +899,7 @@ __device__ __forceinline__ int cost_class(float nst, float demand_over_mu) {
 // 16 lanes per QP, one stage per lane: the loads of a QP go out together, DPP row reductions take the maximum demand and
 // the stance count, lane 0 files the QP.  The class counters are bumped once per workgroup of 64 QPs (a global atomic
 // per QP on a handful of addresses serialises).
-template <typename TIO, bool GAIT>
+template <typename TIO>
 __global__ void __launch_bounds__(1024)
 mpcqp_order_kernel(const FastIn<TIO> in, const int B, const OrderBuf ob) {
   constexpr int N = FG::N;
@@ -953,25 +910,11 @@ mpcqp_order_kernel(const FastIn<TIO> in, const int B, const OrderBuf ob) {
   float score = 0.f, cnt = 0.f;
   if (b < B && k < N) {
     float fx[4], fy[4], fz[4]; bool st[4]; int nst = 0;
-    int sidx = 0; bool all_stance = false;
-    if (GAIT) {   // stage k of the horizon: which planned step it falls in, and whether that step is in its swing phase
-      const int tis = in.gait[(size_t)b * 4], ss = in.gait[(size_t)b * 4 + 1], ds = in.gait[(size_t)b * 4 + 2];
-      int tau = tis + k;
-      if (tau >= ss + ds) { tau -= ss + ds; sidx = 1; }
-      all_stance = tau >= ss;
-    }
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
-      if (!GAIT) {
-        const TIO* rp = in.r + ((size_t)b * N + k) * 12 + 3 * l;
-        fx[l] = (float)rp[0]; fy[l] = (float)rp[1]; fz[l] = (float)rp[2];
-        st[l] = in.contact[((size_t)b * N + k) * 4 + l] != 0;
-      } else {   // planned footholds around the reference com (its drift over the horizon is ignored here)
-        const TIO* fp = in.footholds + (size_t)b * 24 + sidx * 12 + 3 * l;
-        fx[l] = (float)fp[0] - (float)in.ref[(size_t)b * 10 + 3]; fy[l] = (float)fp[1] - (float)in.ref[(size_t)b * 10 + 4];
-        fz[l] = (float)fp[2] - (float)in.ref[(size_t)b * 10 + 5];
-        st[l] = all_stance || in.feet_id[(size_t)b * 8 + sidx * 4 + l] != 0;
-      }
+      const TIO* rp = in.r + ((size_t)b * N + k) * 12 + 3 * l;
+      fx[l] = (float)rp[0]; fy[l] = (float)rp[1]; fz[l] = (float)rp[2];
+      st[l] = in.contact[((size_t)b * N + k) * 4 + l] != 0;
       nst += st[l] ? 1 : 0;
     }
     score = support_demand(nst, fx, fy, fz, st);
@@ -1003,7 +946,7 @@ mpcqp_order_kernel(const FastIn<TIO> in, const int B, const OrderBuf ob) {
 // the device): the grid is only as large as the device holds at once (2 workgroups per CU) and every workgroup pulls
 // QPs from the dearest-first order until the queue is empty -- no workgroup turnover between QPs, and the long solves
 // start first.  Every wave leaves the loop when the queue index passes B (bounded by the `guard` count as well).
-template <typename TV, typename TIO, bool GAIT>
+template <typename TV, typename TIO>
 __global__ void __launch_bounds__(FG::NT, MPCQP_FAST_WPE)
 mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ ctab, const FastIn<TIO> in,
                  TIO* ug, TIO* __restrict__ Xg, int* __restrict__ statusg, int* __restrict__ itersg,
@@ -1028,7 +971,7 @@ mpcqp_fast_solve(const DevCfg* __restrict__ cfgp, const double* __restrict__ cta
 #ifdef MPCQP_STAMPS
     const unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (ph_setup<TV, TIO, GAIT>(cfgp, ctab, in, b, guard == 0 ? 1 : 0)) {   // non-finite input -> zero outputs, status -1
+    if (ph_setup<TV, TIO>(cfgp, ctab, in, b, guard == 0 ? 1 : 0)) {   // non-finite input -> zero outputs, status -1
       for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
       if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (N + 1) * 13 + i] = (TIO)0;
       if (tid == 0) {

@@ -3,17 +3,15 @@
 // Replaces, for a batch of B independent robots, the solve the reference performs once per control tick:
 // CasADi Opti('conic') -> OSQP on the QP of src/mpc.py:58-173, filled at src/mpc.py:242-255, solved at :258.
 //
-// This translation unit is the C-ABI of include/mpcqp.h and the dispatch between two device implementations:
-//   mpcqp_fast.h     horizon 10, ADMM + polish, fp32 matrix tiles with fp64 / fp32 structured residuals: one kernel whose
-//                    phases are separately register-allocated noinline device functions on a file-scope LDS block
-//   mpcqp_general.h  every other configuration (F64, ADMM-only, alpha = 0, horizon 20): one inlined state-machine kernel
-//   mpcqp_device.h   what they share: closed-form model pieces, the O(N) rollout + adjoint gradient, DPP reductions
-// Common design (DESIGN.md has the derivations): one QP per workgroup; the n x n system matrix (n = 12 N force variables)
-// never touches LDS or HBM -- it is built from closed forms straight into register tiles (the single-rigid-body A is
-// nilpotent, so H = 2 alpha I + 2 sum_{stage pairs} c1 P_i.P_i' + c0 Q_i.Q_i' with 6-vectors per force variable), inverted
-// in place by a symmetric sweep (one LDS broadcast + one barrier per pivot), and applied as register-tile x LDS-vector
-// products with DPP butterfly sums; gradients / residuals / predicted states come from an O(N) rollout + adjoint in
-// the vector precision; an OSQP-style active-set polish with a KKT check delivers the digits.
+// This translation unit is the C-ABI of include/mpcqp.h and the dispatch between three device implementations:
+//   mpcqp_wrench.h   the engine: wrench-space (Woodbury) form, H = 2 alpha I + T'KT with a 6N x 6N system, one QP per wave
+//                    (horizon 10) or per four waves (horizon 20), fp32 or fp64 ADMM, fp64 active-set polish, ADMM-only mode
+//   mpcqp_fast.h     round-1 horizon-10 kernel (120 x 120 closed-form register tiles over three waves): all-fp32 arithmetic,
+//                    weights the wrench form does not admit, MPCQP_FLAG_TILE_KERNEL
+//   mpcqp_general.h  round-1 single-launch state machine: alpha = 0 with polish requested, horizon 20 in fp32
+//   mpcqp_device.h   what they share: DPP reductions, the O(N) rollout + adjoint gradient of the round-1 kernels
+// plus the element-wise kernels around the solve: gait-descriptor expansion, closed-loop roll-out (expand / advance), torque map.
+// DESIGN.md has the derivations.
 
 #include "mpcqp_general.h"
 #include "mpcqp_fast.h"
@@ -178,7 +176,7 @@ struct mpcqp_engine {
   void* gait_mem = nullptr;   // gait entry point: the expanded operator tuple [r | xdes | contact] of the current batch
   int64_t gait_cap = 0;
   bool wrench_ok = false;     // the configuration admits the wrench-space form (isotropic omega weight, positive velocity weights)
-  float* dual_mem = nullptr;  // warm-started engines: multipliers of the previous solve per batch slot [dual_cap][200]
+  float* dual_mem = nullptr;  // warm-started engines: multipliers of the previous solve per batch slot [dual_cap][4 N][5]
   int64_t dual_cap = 0;
   bool timed = false;
   bool ev0_set = false;       // the gait entry point has already recorded the start event (in front of its expansion kernel)
@@ -209,7 +207,7 @@ hipError_t launch(const mpcqp_engine* e, int64_t B, const void* x0, const void* 
 #define MPCQP_DEBUG_DYN_LDS 0   // occupancy experiments only: extra dynamic LDS per workgroup
 #endif
 // Fast path (mpcqp_fast.h): one launch, one QP per workgroup, phases as separately register-allocated device functions.
-template <typename TIO, bool GAIT>
+template <typename TIO>
 hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
                        float* res, hipStream_t s) {
   dim3 grid((unsigned)B);
@@ -219,21 +217,21 @@ hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* 
     ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 32; ob.cap = e->order_cap;
     hipError_t he = hipMemsetAsync(ob.cnt, 0, 32 * sizeof(int), s);
     if (he != hipSuccess) return he;
-    hipLaunchKernelGGL((mpcqp_order_kernel<TIO, GAIT>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
+    hipLaunchKernelGGL((mpcqp_order_kernel<TIO>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
     grid = dim3((unsigned)(B < e->slots ? B : e->slots));   // queued form: resident workgroups pull QPs
   }
   if (e->cfg.precision == MPCQP_PREC_MIXED)
-    hipLaunchKernelGGL((mpcqp_fast_solve<double, TIO, GAIT>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
+    hipLaunchKernelGGL((mpcqp_fast_solve<double, TIO>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
                        st, it, res, ob, (int)B);
   else
-    hipLaunchKernelGGL((mpcqp_fast_solve<float, TIO, GAIT>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
+    hipLaunchKernelGGL((mpcqp_fast_solve<float, TIO>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
                        st, it, res, ob, (int)B);
   return hipGetLastError();
 }
 
 // Wrench-space engine (mpcqp_wrench.h).  Horizon 10: one QP per wave, 2 waves per SIMD = 8 resident workgroups per CU, queued
 // launch form for batches that oversubscribe them.  Horizon 20: one QP per 4-wave workgroup, plain launch form.
-template <typename TIO, bool GAIT, int N>
+template <typename TIO, int N>
 hipError_t launch_wrench(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
                          float* res, hipStream_t s) {
   dim3 grid((unsigned)B);
@@ -244,26 +242,25 @@ hipError_t launch_wrench(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void
       ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 32; ob.cap = e->order_cap;
       hipError_t he = hipMemsetAsync(ob.cnt, 0, 32 * sizeof(int), s);
       if (he != hipSuccess) return he;
-      hipLaunchKernelGGL((mpcqp_order_kernel<TIO, GAIT>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
+      hipLaunchKernelGGL((mpcqp_order_kernel<TIO>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
       grid = dim3((unsigned)slots);
     }
   }
   const WrTabs tabs = {e->wr_K, e->wr_kinv32, e->wr_kinv64};
   if (e->cfg.precision == MPCQP_PREC_MIXED)
-    hipLaunchKernelGGL((mpcqp_wrench_solve<double, float, double, TIO, N, GAIT>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
+    hipLaunchKernelGGL((mpcqp_wrench_solve<double, float, double, TIO, N>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
                        (TIO*)X, st, it, res, ob, (int)B);
   else
-    hipLaunchKernelGGL((mpcqp_wrench_solve<double, double, double, TIO, N, GAIT>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
+    hipLaunchKernelGGL((mpcqp_wrench_solve<double, double, double, TIO, N>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
                        (TIO*)X, st, it, res, ob, (int)B);
   return hipGetLastError();
 }
 
-template <typename TIO, bool GAIT>
+template <typename TIO>
 hipError_t launch_wrench_n(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
                            float* res, hipStream_t s) {
-  static_assert(!GAIT, "the gait entry point expands its descriptors into a tuple first");
-  if (e->cfg.N == 10) return launch_wrench<TIO, false, 10>(e, B, in, u, X, st, it, res, s);
-  return launch_wrench<TIO, false, 20>(e, B, in, u, X, st, it, res, s);
+  if (e->cfg.N == 10) return launch_wrench<TIO, 10>(e, B, in, u, X, st, it, res, s);
+  return launch_wrench<TIO, 20>(e, B, in, u, X, st, it, res, s);
 }
 
 // Workspace that depends on the batch size: the dispatch-order buffer of the queued launch forms and, for warm-started
@@ -283,10 +280,11 @@ int reserve_workspace(mpcqp_engine* e, int64_t B) {
   }
   if ((e->cfg.flags & MPCQP_FLAG_WARM_START) && e->dual_cap < B) {
     float* mem = nullptr;
-    if (hipMalloc(&mem, (size_t)B * 200 * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return MPCQP_ENOMEM; }
+    const size_t per = (size_t)20 * e->cfg.N;   // 4 N leg-stages x 5 rows
+    if (hipMalloc(&mem, (size_t)B * per * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return MPCQP_ENOMEM; }
     (void)hipDeviceSynchronize();
-    (void)hipMemset(mem, 0, (size_t)B * 200 * sizeof(float));   // new slots start at zero = no record
-    if (e->dual_mem) { (void)hipMemcpy(mem, e->dual_mem, (size_t)e->dual_cap * 200 * sizeof(float), hipMemcpyDeviceToDevice); (void)hipFree(e->dual_mem); }
+    (void)hipMemset(mem, 0, (size_t)B * per * sizeof(float));   // new slots start at zero = no record
+    if (e->dual_mem) { (void)hipMemcpy(mem, e->dual_mem, (size_t)e->dual_cap * per * sizeof(float), hipMemcpyDeviceToDevice); (void)hipFree(e->dual_mem); }
     e->dual_mem = mem; e->dual_cap = B;
   }
   return MPCQP_OK;
@@ -557,13 +555,13 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
     if (h->cfg.dtype == MPCQP_DTYPE_F64) {
       const FastIn<double> in = {(const double*)x0, (const double*)r, contact, (const double*)xdes, (const double*)mu,
                                  nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const double*)u_out : nullptr, ys, shift};
-      he = wrench ? launch_wrench_n<double, false>(h, B, in, u_out, X_out, status, iters, res, st)
-                  : launch_fast<double, false>(h, B, in, u_out, X_out, status, iters, res, st);
+      he = wrench ? launch_wrench_n<double>(h, B, in, u_out, X_out, status, iters, res, st)
+                  : launch_fast<double>(h, B, in, u_out, X_out, status, iters, res, st);
     } else {
       const FastIn<float> in = {(const float*)x0, (const float*)r, contact, (const float*)xdes, (const float*)mu,
                                 nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const float*)u_out : nullptr, ys, shift};
-      he = wrench ? launch_wrench_n<float, false>(h, B, in, u_out, X_out, status, iters, res, st)
-                  : launch_fast<float, false>(h, B, in, u_out, X_out, status, iters, res, st);
+      he = wrench ? launch_wrench_n<float>(h, B, in, u_out, X_out, status, iters, res, st)
+                  : launch_fast<float>(h, B, in, u_out, X_out, status, iters, res, st);
     }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
   } else if (B > 0) {

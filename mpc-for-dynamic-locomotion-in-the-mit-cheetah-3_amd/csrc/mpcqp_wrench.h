@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void w_output(SmemW<TV, N>& s, const WrTabs& tabs, TI
 // ----------------------------------------------------------------------------------------------------- the kernel
 // Plain form: blockIdx = QP.  Queued form (ob.list != null): resident workgroups pull QPs dearest-expected-first from
 // the queue the pre-pass of mpcqp_fast.h fills; every wave leaves when the queue index passes Btot.
-template <typename TV, typename TM, typename TP, typename TIO, int N, bool GAIT>
+template <typename TV, typename TM, typename TP, typename TIO, int N>
 __global__ void __launch_bounds__(WG<N>::NT, 2)
 mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const FastIn<TIO> in, TIO* ug, TIO* __restrict__ Xg,
                    int* __restrict__ statusg, int* __restrict__ itersg, float* __restrict__ resg, const OrderBuf ob, const int Btot) {

@@ -96,6 +96,23 @@ def test_admm_only_mode(oracle_solve, N, precision):
     assert rel_err(out["u"], ref["u"])[conv].max() <= tol
 
 
+def test_horizon20_warm_start_same_optimum(oracle_solve):
+    """Warm start at N = 20 (per-slot multiplier record of 4 N x 5 rows): restarting from the optimum costs no ADMM block, and
+    the answer is the cold one."""
+    b = mpcqp.synth.config5(96)
+    cold = gpu_solve(b, N=20, io="f64", precision="mixed")
+    sol = mpcqp.MPCBatch(N=20, delta=0.03, io_dtype="f64", precision="mixed", warm_start=True)
+    dev = sol.upload(b)
+    o1 = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"]); torch.cuda.synchronize()
+    u1 = o1["u"].cpu().numpy().copy(); it1 = o1["iters"].cpu().numpy().copy()
+    o2 = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"]); torch.cuda.synchronize()   # seeded with its own solution
+    u2 = o2["u"].cpu().numpy(); it2 = o2["iters"].cpu().numpy(); st2 = o2["status"].cpu().numpy()
+    ok = solved(cold["status"]) & solved(st2)
+    assert ok.mean() >= 0.97
+    assert rel_err(u1, cold["u"])[ok].max() <= 1e-6 and rel_err(u2, cold["u"])[ok].max() <= 1e-4
+    assert (it2 % 1000)[ok].mean() < 0.2 * (it1 % 1000)[ok].mean()          # (nearly) no ADMM iterations on the restart
+
+
 def test_two_rank_bench_rehearsal():
     """bench.py --gpus 2 (gloo, both ranks on this one GPU), launched as a fresh child before this process initialised HIP."""
     rc, stdout, stderr = bench2_result()
