@@ -88,7 +88,9 @@ typedef struct MpcQpConfig {
   double m;             /* 8.885 (src/mpc.py:71) */
   double Ibody_inv[3];  /* diag(1/0.24, 1, 1) (src/mpc.py:73-76) */
   double w[13];         /* state weights (src/mpc.py:122-134) */
-  double alpha;         /* force weight; 0.0 in the reference (src/mpc.py:121) */
+  double alpha;         /* force weight; 0.0 in the reference (src/mpc.py:121).  Below 1e-2 the engine solves at 1e-2 and walks the
+                           weight down by continuation; 0.0 ends at 3e-6 (objective / states / net wrench of the alpha = 0 optimum
+                           to 1e-6 / 1e-4 / 1e-4; the forces themselves are not unique at 0) */
   double f_min, f_max;  /* 3, 100 (src/mpc.py:45-46) */
   int32_t disc;         /* MPCQP_DISC_* */
   int32_t dtype;        /* MPCQP_DTYPE_* of the caller's buffers */

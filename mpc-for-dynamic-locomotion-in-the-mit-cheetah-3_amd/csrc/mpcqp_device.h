@@ -42,6 +42,7 @@ struct DevCfg {
   double delta, inv_m, Ib[3], w[12], sw[12], alpha, fmin, fmax, rho, sigma, relax, eps_abs, eps_rel, theta;
   int max_iter, check_every, polish_max;
   unsigned flags;
+  double alpha_floor;   // wrench engine: where the regulariser continuation of an alpha = 0 request ends
 };
 
 // Problem constants staged in LDS in the vector precision (keeps ~100 scalar registers free).

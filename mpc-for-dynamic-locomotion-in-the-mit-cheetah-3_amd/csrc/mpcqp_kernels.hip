@@ -18,6 +18,7 @@
 #include "mpcqp_wrench.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -312,9 +313,8 @@ struct DeviceGuard {
 };
 
 bool wrench_path_applies(const mpcqp_engine* h) {
-  return h->wrench_ok && h->cfg.precision != MPCQP_PREC_F32 &&
-         !(h->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL)) &&
-         (h->cfg.alpha > 0.0 || !(h->cfg.flags & MPCQP_FLAG_POLISH));   // (the polish system is D = 2 alpha + T'KT: needs alpha > 0)
+  // (any alpha >= 0: a request below 1e-2 -- the reference's own 0.0 included -- is served by continuation, mpcqp_wrench.h)
+  return h->wrench_ok && h->cfg.precision != MPCQP_PREC_F32 && !(h->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL));
 }
 
 bool fast_path_applies(const mpcqp_engine* h) {
@@ -486,6 +486,8 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   d.theta = cfg->disc == MPCQP_DISC_ZOH ? 0.5 : 0.0;
   d.max_iter = cfg->max_iter; d.check_every = cfg->check_every; d.polish_max = cfg->polish_max;
   d.flags = cfg->flags;
+  d.alpha_floor = ALPHA_FLOOR;
+  if (const char* ev = getenv("MPCQP_ALPHA_FLOOR")) { const double v = atof(ev); if (v > 0) d.alpha_floor = v; }   // developer knob
 
   // coefficient tables: c0[j][j'] = delta^2 (N - max(j,j')),
   // c1[j][j'] = delta^4 sum_{k > max(j,j')}^{N} (k-1-j+theta)(k-1-j'+theta)

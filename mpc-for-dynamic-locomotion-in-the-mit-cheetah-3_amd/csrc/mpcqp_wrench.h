@@ -49,6 +49,7 @@ struct SmemW {
   TV rzw0[3];
   TV wP[6], wQ[6];
   TV delta, theta, alpha, inv_m, fmin, fmax;
+  TV alpha_ok;                   // continuation: the last regulariser level whose optimum was accepted
   TV Bl[Geo::NL * 9];            // per leg-stage: Rz Ihat^-1 [r]x, masked by contact (row i = angular component, col a = force axis)
   TV cm[Geo::NL];                // contact / m
   TV gam[Geo::NQ];               // gradient of the cost in wrench space at u = 0
@@ -479,7 +480,7 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
   if (first) {
     if (tid < 6) { s.wP[tid] = (TV)cfg.w[tid]; s.wQ[tid] = (TV)cfg.w[6 + tid]; }
     if (tid == 0) {
-      s.delta = (TV)cfg.delta; s.theta = (TV)cfg.theta; s.alpha = (TV)cfg.alpha; s.inv_m = (TV)cfg.inv_m;
+      s.delta = (TV)cfg.delta; s.theta = (TV)cfg.theta; s.inv_m = (TV)cfg.inv_m;
       s.fmin = (TV)cfg.fmin; s.fmax = (TV)cfg.fmax;
     }
     for (int i = tid; i < DP; i += NT) { s.bv[i] = 0.0; s.cv[i] = 0.0; s.piv[i] = 0.0; s.piv[DP + i] = 0.0; }   // pad slots stay finite
@@ -573,6 +574,7 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
   }
   wmax<1, NW>(q, s.red, tid);
   if (tid == 0) { s.gmax = q[0]; s.rho = (float)cfg.rho; s.iters = 0; s.psteps = 0; s.hard = 0; s.warm = 0; }
+  // (s.alpha: set by the kernel before the setup -- the regulariser the solve STARTS with, see the continuation in the kernel)
   wsync<NW>();
 #if defined(MPCQP_STAMPS) || defined(MPCQP_WDBG)
   if (b == 0) {   // diagnostic build only: the first QP's setup products
@@ -721,6 +723,8 @@ __device__ __forceinline__ float w_ratio_lds(SmemW<TV, N>& s, const WrTabs& tabs
   return w_ratio<TV, N>(s, tabs, u, z, y, g, s.mu, tid < NL, tid);
 }
 
+constexpr double ALPHA_EASY = 1e-2;     // regulariser at which the active-set search is done (continuation start)
+constexpr double ALPHA_FLOOR = 3e-6;    // where a request for alpha = 0 ends (tools/alpha0_floor.py: 1e-5 leaves the net wrench 2e-4 off, 1e-6 stalls)
 #ifndef MPCQP_W_POLISH_PATIENCE
 #define MPCQP_W_POLISH_PATIENCE 1
 #endif
@@ -740,7 +744,7 @@ __device__ __forceinline__ void w_admm_sys(const SmemW<TV, N>& s, const DevCfg& 
 #pragma unroll
     for (int a = 0; a < 3; ++a) Ls.A[c][3 + a] = a == c ? (TM)s.cm[L] : (TM)0;
   }
-  const TM r = (TM)rho, m = (TM)s.mu, a2 = (TM)(2.0 * cfg.alpha), sigma = (TM)cfg.sigma;
+  const TM r = (TM)rho, m = (TM)s.mu, a2 = (TM)((TV)2 * s.alpha), sigma = (TM)cfg.sigma;
   Ls.dinv[0] = Ls.dinv[1] = stance ? (TM)1 / (a2 + sigma + (TM)2 * r) : (TM)0;
   Ls.dinv[2] = stance ? (TM)1 / (a2 + sigma + r * ((TM)1 + (TM)4 * m * m)) : (TM)0;
 }
@@ -976,11 +980,15 @@ __device__ __forceinline__ int w_polish(SmemW<TV, N>& s, const WrTabs& tabs, con
     wsync<NW>();
     w_grad<TV, N>(s, tabs.K, tid, gr3);
     TV rg[3] = {ex ? gr3[0] : (TV)0, ey ? gr3[1] : (TV)0, ez ? gr3[2] + txs * gr3[0] + tys * gr3[1] : (TV)0};
-    float q[1] = {leg ? fmaxf(fmaxf(fabsf((float)rg[0]), fabsf((float)rg[1])), fabsf((float)rg[2])) : 0.f};
+    float q[2] = {leg ? fmaxf(fmaxf(fabsf((float)rg[0]), fabsf((float)rg[1])), fabsf((float)rg[2])) : 0.f,
+                  leg ? fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2])) : 0.f};
     if (!isfinite(q[0])) q[0] = INFINITY;
-    wmax<1, NW>(q, s.red, tid);
+    wmax<2, NW>(q, s.red, tid);
     prev = stat; stat = q[0];
-    if (stat <= tol_stat || rf >= 4 || (rf > 0 && !(stat < 0.5f * prev))) break;   // converged / stagnated (uniform)
+    // refine until the stationarity residual is safely below what the acceptance test will ask for (it scales with 2 alpha:
+    // binding for alpha < 1e-2, where one fp64 solve -- residual ~1e-9 |g| -- is not enough)
+    const float tol = fminf(tol_stat, 0.25f * ((sizeof(TV) == 8) ? 2.f * (float)s.alpha : 1e30f) * 2e-5f * fmaxf(1.f, q[1]));
+    if (stat <= tol || rf >= 4 || (rf > 0 && !(stat < 0.5f * prev))) break;   // converged / stagnated (uniform)
     const TP rhs[3] = {(TP)(-rg[0]), (TP)(-rg[1]), (TP)(-rg[2])};
     TP dx[3];
     {
@@ -1137,6 +1145,15 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
 #else
     const bool first_qp = guard == 0;
 #endif
+    // Regulariser continuation: a request below ALPHA_EASY (the reference's own cost has alpha = 0, src/mpc.py:121) is solved at
+    // ALPHA_EASY first -- the well-conditioned problem every QP of the bench workload solves -- and then walked down by factors of
+    // ten with polish steps from the previous level's optimum and multipliers (the active set barely moves between levels,
+    // while a cold active-set search at alpha <= 1e-4 cycles on the nearly flat force-distribution directions).  alpha = 0 ends
+    // at ALPHA_FLOOR: objective within 1e-7 relative, states and net wrench within 1e-4 of the alpha = 0 optimum (tools/alpha0_floor.py),
+    // forces = (nearly) the minimum-norm member of the non-unique optimal set.
+    const TV alpha_target = (TV)(cfg.alpha > 0.0 ? cfg.alpha : ((cfg.flags & MPCQP_FLAG_POLISH) ? cfg.alpha_floor : 0.0));
+    const TV alpha_start = ((cfg.flags & MPCQP_FLAG_POLISH) && cfg.alpha < ALPHA_EASY) ? (TV)ALPHA_EASY : (TV)cfg.alpha;
+    if (tid == 0) s.alpha = alpha_start;
     if (w_setup<TV, TIO, N>(s, cfg, tabs, in, b, tid, first_qp)) {   // non-finite input -> zero outputs, status -1
       for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
       if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (size_t)(N + 1) * 13 + i] = (TIO)0;
@@ -1153,43 +1170,70 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
     const int max_iter = cfg.max_iter, polish_max = cfg.polish_max;
     int ok = 0;
     const int warm = s.warm;
-    // Round -1 exists only for a warm start: polish steps on the guess's own active set before any ADMM block.  (One loop,
-    // so that the polish and the ADMM block are each inlined exactly once: the kernel's code has to stay inside the
-    // instruction cache that the waves of two CUs share.)
+    // One loop, three kinds of round, so that the polish and the ADMM block are each inlined exactly once (the kernel's code has
+    // to stay inside the instruction cache that the waves of two CUs share):
+    //   WARM   (warm start only) polish steps on the guess's own active set before any ADMM block
+    //   ADMM   an ADMM block, then polish steps; on failure OSQP's rho adaptation and another round until max_iter is spent
+    //   CONT   (continuation) the regulariser has just been lowered: polish steps from the previous level's optimum
+    enum { R_WARM, R_ADMM, R_CONT };
     const int warm_tries = !(cfg.flags & MPCQP_FLAG_POLISH) ? 0 : (warm == 1 ? WARM_POLISH : (warm == 2 ? 1 : 0));
-    for (int round = warm_tries > 0 ? -1 : 0; !ok; ++round) {
-      int budget = min(warm_tries, polish_max);
-      if (round >= 0) {
-        if (round > 0) {   // not solved: OSQP's rho adaptation from the residuals of the last ADMM iterate, then another block
-          const float ratio = w_ratio_lds<TV, N>(s, tabs, tid);
-          // (tolerance 2 between ADMM + polish rounds; OSQP's own 5 when ADMM has to converge by itself: frequent changes of
-          //  the penalty stall the tail of a long ADMM run)
-          const float rtol = (cfg.flags & MPCQP_FLAG_POLISH) ? 2.f : 5.f;
-          if (tid == 0 && isfinite(ratio) && (ratio > rtol || ratio < 1.f / rtol)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
-          wsync<NW>();
-        }
+    int kind = warm_tries > 0 ? R_WARM : R_ADMM, round = 0, cont_retry = 0;
+    for (;;) {
+      int budget = kind == R_WARM ? min(warm_tries, polish_max) : 2 * polish_max;
+      const bool admm_only = !(cfg.flags & MPCQP_FLAG_POLISH);
+      if (kind == R_ADMM) {
         w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, (round == 0 && warm >= 2) ? WARM_K : 0, tid);
-        budget = (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
-        if (!(cfg.flags & MPCQP_FLAG_POLISH)) {   // ADMM only (OSQP's own termination test, the reference leaves polish off, src/mpc.py:51-55)
-          (void)w_ratio_lds<TV, N>(s, tabs, tid);
-          wsync<NW>();
-          const float tp = (float)cfg.eps_abs + (float)cfg.eps_rel * s.resid[2], td = (float)cfg.eps_abs + (float)cfg.eps_rel * s.resid[3];
-          if (s.resid[0] <= tp && s.resid[1] <= td) ok = 2;
-          if (tid == 0) { s.kkt[0] = s.resid[1]; s.kkt[1] = s.resid[0]; s.kkt[2] = 0.f; }
-          budget = 0;
-        }
+        budget = admm_only ? 0 : (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
       }
       // Active-set steps while they make progress: a step that does not at least halve the KKT violation of the previous one
       // (primal + dual-sign, each relative to its scale) means ADMM has not settled the active set yet -- back to ADMM rather
       // than through the rest of the budget (each step costs an fp64 sweep, about 50 ADMM iterations).
+      const bool last = kind != R_ADMM || s.iters >= max_iter;   // (a round that nothing follows keeps its full budget)
       float vprev = INFINITY;
       for (int ps = 0; ps < budget && !ok; ++ps) {
         ok = w_polish<TV, TP, N>(s, tabs, kinvP, tid);
         const float v = s.kkt[1] + s.kkt[2] / fmaxf(s.gmax, 1.f) * 100.f;
-        if (!ok && ps >= POLISH_PATIENCE && !(v < 0.5f * vprev) && (round < 0 || s.iters < max_iter)) break;   // uniform (the last round keeps its full budget)
+        if (!ok && ps >= POLISH_PATIENCE && !(v < 0.5f * vprev) && !last) break;   // uniform
         vprev = v;
       }
-      if (ok || (round >= 0 && s.iters >= max_iter)) break;
+      if (ok == 1 && s.alpha > alpha_target) {   // next continuation level, from this optimum and its multipliers
+        for (int i = tid; i < n; i += NT) s.ua[i] = s.uv[i];            // the last accepted answer and its multipliers (the ADMM
+        for (int i = tid; i < WG<N>::NL * 5; i += NT) s.ya[i] = s.py[i];   // iterate is not needed any more)
+        if (tid == 0) { s.alpha_ok = s.alpha; s.alpha = fmax(s.alpha * (TV)0.1, alpha_target); }
+        wsync<NW>();
+        ok = 0; cont_retry = 0;
+        kind = R_CONT;
+        continue;
+      }
+      if (ok) break;
+      if (kind == R_CONT) {   // level not reached: back to the last accepted point and a smaller step (geometric bisection), a few times
+        if (++cont_retry > 3) { ok = 3; break; }                         // ... then the previous level's answer, status MAX_ITER
+        for (int i = tid; i < n; i += NT) s.pu[i] = s.ua[i];
+        for (int i = tid; i < WG<N>::NL * 5; i += NT) s.py[i] = s.ya[i];
+        if (tid == 0) s.alpha = sqrt(s.alpha_ok * s.alpha);
+        wsync<NW>();
+        continue;
+      }
+      if (kind == R_WARM) { kind = R_ADMM; continue; }
+      if (!admm_only && s.iters >= max_iter) break;
+      {   // residuals of the last ADMM iterate: OSQP's termination test (ADMM only -- what the reference runs, polish off,
+          // src/mpc.py:51-55) and its rho adaptation for the next block
+        const float ratio = w_ratio_lds<TV, N>(s, tabs, tid);
+        wsync<NW>();
+        if (admm_only) {
+          const float tp = (float)cfg.eps_abs + (float)cfg.eps_rel * s.resid[2], td = (float)cfg.eps_abs + (float)cfg.eps_rel * s.resid[3];
+          if (s.resid[0] <= tp && s.resid[1] <= td) ok = 2;
+          wsync<NW>();
+          if (tid == 0) { s.kkt[0] = s.resid[1]; s.kkt[1] = s.resid[0]; s.kkt[2] = 0.f; }
+          if (ok || s.iters >= max_iter) break;
+        }
+        // (tolerance 2 between ADMM + polish rounds; OSQP's own 5 when ADMM has to converge by itself: frequent changes of the
+        //  penalty stall the tail of a long ADMM run)
+        const float rtol = admm_only ? 5.f : 2.f;
+        if (tid == 0 && isfinite(ratio) && (ratio > rtol || ratio < 1.f / rtol)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
+        wsync<NW>();
+      }
+      ++round;
     }
     w_output<TV, TIO, N>(s, tabs, ug, Xg, statusg, itersg, resg, in.y_state, b, ok, tid);
 #ifdef MPCQP_STAMPS

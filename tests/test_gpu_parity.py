@@ -93,19 +93,51 @@ def test_golden_log_ticks(golden):
         assert np.abs(out["X"][ok] - opt[f"N{N}_a1e-2_X"][ok]).max() <= 1e-4
 
 
-def test_alpha0_reference_cost_unique_quantities(golden):
-    """The reference's own cost (alpha = 0): GRFs are not unique; objective and predicted states are.
-    ADMM only (polish needs alpha > 0); tolerance: objective 1e-4 relative, states 2e-3 absolute at K = 4000."""
+@pytest.mark.parametrize("mode", ["continuation", "admm_only"])
+def test_alpha0_reference_cost_unique_quantities(golden, mode):
+    """The reference's own cost (alpha = 0, src/mpc.py:121): GRFs are not unique; objective, predicted states and the per-stage
+    net wrench are.  Default mode (MIXED, polish): the engine walks the regulariser down from 1e-2 to 1e-5 by
+    continuation -- objective <= 1e-6 relative, states and net wrench <= 1e-4 of the alpha = 0 optimum on the golden ticks.
+    ADMM only (fp64, polish off): objective 1e-4 relative, states 2e-3 absolute at K = 4000."""
     q, opt = golden["qp_inputs"], golden["qp_optima"]
     N = 10
     b = {"x0": q[f"N{N}_x0"], "r": q[f"N{N}_r"], "contact": q[f"N{N}_contact"], "xdes": q[f"N{N}_xdes"],
          "mu": np.full(len(q["ticks"]), float(q["mu"]))}
-    out = gpu_solve(b, N=N, delta=float(q["delta"]), precision="f64", alpha=0.0, max_iter=4000, eps_abs=1e-7, eps_rel=1e-7)
     cfg = S.QPConfig(N=N, delta=float(q["delta"]), alpha=0.0)
-    for i in range(len(b["mu"])):
+    if mode == "continuation":
+        out = gpu_solve(b, N=N, delta=float(q["delta"]), precision="mixed", alpha=0.0, max_iter=800)
+        ok = solved(out["status"])
+        assert ok.sum() >= len(ok) - 1
+        tolJ, tolX = 1e-6, 1e-4
+    else:
+        out = gpu_solve(b, N=N, delta=float(q["delta"]), precision="f64", alpha=0.0, flags=0, max_iter=4000, eps_abs=1e-7, eps_rel=1e-7)
+        ok = np.ones(len(b["mu"]), bool)
+        tolJ, tolX = 1e-4, 2e-3
+    for i in np.where(ok)[0]:
         J = S.objective(out["X"][i], out["u"][i], b["xdes"][i], cfg)
-        assert abs(J - opt["N10_a0_J"][i]) <= 1e-4 * max(1.0, abs(opt["N10_a0_J"][i]))
-        assert np.abs(out["X"][i] - opt["N10_a0_X"][i]).max() <= 2e-3
+        assert abs(J - opt["N10_a0_J"][i]) <= tolJ * max(1.0, abs(opt["N10_a0_J"][i])), (i, J, opt["N10_a0_J"][i])
+        assert np.abs(out["X"][i] - opt["N10_a0_X"][i]).max() <= tolX
+        if mode == "continuation":
+            Wn = S.net_wrench(out["u"][i], b["r"][i], b["contact"][i], cfg)
+            assert np.abs(Wn - opt["N10_a0_wrench"][i]).max() <= 1e-4 * max(1.0, np.abs(opt["N10_a0_wrench"][i]).max())
+
+
+def test_alpha0_continuation_on_config3(oracle_solve):
+    """alpha = 0 on the bench distribution: >= 99 % reach the end of the continuation; states and per-stage net wrench within
+    1e-4 of the alpha = 0 optimum (the oracle's ADMM run to 1e-10 on the singular problem)."""
+    B = 96
+    b = mpcqp.synth.config3(B)
+    ref = oracle_solve(b, alpha=0.0, rho=0.3, max_iter=200000)
+    out = gpu_solve(b, precision="mixed", alpha=0.0, max_iter=800)
+    ok = solved(out["status"]) & (ref["status"] != 3)
+    assert solved(out["status"]).mean() >= 0.98
+    cfg = S.QPConfig(N=10, delta=0.03, alpha=0.0)
+    assert np.abs(out["X"][ok] - ref["X"][ok]).max() <= 1e-4
+    for i in np.where(ok)[0]:
+        W, Wr = S.net_wrench(out["u"][i], b["r"][i], b["contact"][i], cfg), S.net_wrench(ref["u"][i], b["r"][i], b["contact"][i], cfg)
+        assert np.abs(W - Wr).max() <= 1e-4 * max(1.0, np.abs(Wr).max())
+        J, Jr = S.objective(out["X"][i], out["u"][i], b["xdes"][i], cfg), S.objective(ref["X"][i], ref["u"][i], b["xdes"][i], cfg)
+        assert abs(J - Jr) <= 1e-6 * max(1.0, abs(Jr))
 
 
 def test_admm_only_converges_to_oracle(oracle_solve):
@@ -249,10 +281,11 @@ def test_torque_map_epilogue():
         assert np.abs(tau.cpu().numpy() - want).max() <= tol * 30
 
 
-@pytest.mark.parametrize("alpha,precision,min_solved", [(1.0, "mixed", 0.99), (1e-3, "mixed", 0.93), (1e-4, "f64", 0.9)])
+@pytest.mark.parametrize("alpha,precision,min_solved", [(1.0, "mixed", 0.99), (1e-3, "mixed", 0.99), (1e-4, "mixed", 0.99), (1e-4, "f64", 0.99)])
 def test_regulariser_sweep(oracle_solve, alpha, precision, min_solved):
     """`solved` must imply the 1e-4 band for any force regulariser alpha (conditioning ~ 1 / alpha): the polish acceptance
-    scales with the curvature 2 alpha.  Small alpha needs the all-fp64 mode (fp32 tiles stop being a contraction)."""
+    scales with the curvature 2 alpha.  Below 1e-2 the engine finds the active set at 1e-2 and walks alpha down by continuation
+    (fp64 polish systems), which keeps the solved fraction at >= 99 % in MIXED as well."""
     b = mpcqp.synth.config3(256)
     ref = oracle_solve(b, alpha=alpha, max_iter=200000)
     out = gpu_solve(b, io="f64", precision=precision, alpha=alpha, max_iter=1000 if precision == "f64" else 400)
