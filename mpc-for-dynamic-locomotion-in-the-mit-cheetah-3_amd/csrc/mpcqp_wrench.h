@@ -49,7 +49,7 @@ struct SmemW {
   TV rzw0[3];
   TV wP[6], wQ[6];
   TV delta, theta, alpha, inv_m, fmin, fmax;
-  TV alpha_ok;                   // continuation: the last regulariser level whose optimum was accepted
+  TV alpha_target, alpha_ok;     // continuation: where it ends; the last regulariser level whose optimum was accepted
   TV Bl[Geo::NL * 9];            // per leg-stage: Rz Ihat^-1 [r]x, masked by contact (row i = angular component, col a = force axis)
   TV cm[Geo::NL];                // contact / m
   TV gam[Geo::NQ];               // gradient of the cost in wrench space at u = 0
@@ -1120,12 +1120,12 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
     if (ob.list) {
       if (tid == 0) s_next = atomicAdd(ob.head, 1);
       __syncthreads();
-      int i = s_next;
+      int i = __builtin_amdgcn_readfirstlane(s_next);
       __syncthreads();
       if (i >= Btot) break;                  // uniform
       for (int k = ORDER_BUCKETS - 1; k >= 0; --k) {
         const int c = ob.cnt[k];
-        if (i < c) { b = (size_t)ob.list[(size_t)k * ob.cap + i]; break; }
+        if (i < c) { b = (size_t)__builtin_amdgcn_readfirstlane(ob.list[(size_t)k * ob.cap + i]); break; }
         i -= c;
       }
     }
@@ -1151,9 +1151,11 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
     // while a cold active-set search at alpha <= 1e-4 cycles on the nearly flat force-distribution directions).  alpha = 0 ends
     // at ALPHA_FLOOR: objective within 1e-7 relative, states and net wrench within 1e-4 of the alpha = 0 optimum (tools/alpha0_floor.py),
     // forces = (nearly) the minimum-norm member of the non-unique optimal set.
-    const TV alpha_target = (TV)(cfg.alpha > 0.0 ? cfg.alpha : ((cfg.flags & MPCQP_FLAG_POLISH) ? cfg.alpha_floor : 0.0));
-    const TV alpha_start = ((cfg.flags & MPCQP_FLAG_POLISH) && cfg.alpha < ALPHA_EASY) ? (TV)ALPHA_EASY : (TV)cfg.alpha;
-    if (tid == 0) s.alpha = alpha_start;
+    // (both kept in LDS, not in registers: whatever lives across the fp64 sweep is spilled)
+    if (tid == 0) {
+      s.alpha_target = (TV)(cfg.alpha > 0.0 ? cfg.alpha : ((cfg.flags & MPCQP_FLAG_POLISH) ? cfg.alpha_floor : 0.0));
+      s.alpha = ((cfg.flags & MPCQP_FLAG_POLISH) && cfg.alpha < ALPHA_EASY) ? (TV)ALPHA_EASY : (TV)cfg.alpha;
+    }
     if (w_setup<TV, TIO, N>(s, cfg, tabs, in, b, tid, first_qp)) {   // non-finite input -> zero outputs, status -1
       for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
       if (Xg) for (int i = tid; i < (N + 1) * 13; i += NT) Xg[b * (size_t)(N + 1) * 13 + i] = (TIO)0;
@@ -1169,7 +1171,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
     STAMP(0);
     const int max_iter = cfg.max_iter, polish_max = cfg.polish_max;
     int ok = 0;
-    const int warm = s.warm;
+    const int warm = __builtin_amdgcn_readfirstlane(s.warm);
     // One loop, three kinds of round, so that the polish and the ADMM block are each inlined exactly once (the kernel's code has
     // to stay inside the instruction cache that the waves of two CUs share):
     //   WARM   (warm start only) polish steps on the guess's own active set before any ADMM block
@@ -1183,23 +1185,23 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       const bool admm_only = !(cfg.flags & MPCQP_FLAG_POLISH);
       if (kind == R_ADMM) {
         w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, (round == 0 && warm >= 2) ? WARM_K : 0, tid);
-        budget = admm_only ? 0 : (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
+        budget = admm_only ? 0 : (__builtin_amdgcn_readfirstlane(s.hard) ? HARD_POLISH_FACTOR : 1) * polish_max;
       }
       // Active-set steps while they make progress: a step that does not at least halve the KKT violation of the previous one
       // (primal + dual-sign, each relative to its scale) means ADMM has not settled the active set yet -- back to ADMM rather
       // than through the rest of the budget (each step costs an fp64 sweep, about 50 ADMM iterations).
-      const bool last = kind != R_ADMM || s.iters >= max_iter;   // (a round that nothing follows keeps its full budget)
+      const bool last = kind != R_ADMM || __builtin_amdgcn_readfirstlane(s.iters) >= max_iter;   // (a round that nothing follows keeps its full budget)
       float vprev = INFINITY;
       for (int ps = 0; ps < budget && !ok; ++ps) {
-        ok = w_polish<TV, TP, N>(s, tabs, kinvP, tid);
+        ok = __builtin_amdgcn_readfirstlane(w_polish<TV, TP, N>(s, tabs, kinvP, tid));
         const float v = s.kkt[1] + s.kkt[2] / fmaxf(s.gmax, 1.f) * 100.f;
         if (!ok && ps >= POLISH_PATIENCE && !(v < 0.5f * vprev) && !last) break;   // uniform
         vprev = v;
       }
-      if (ok == 1 && s.alpha > alpha_target) {   // next continuation level, from this optimum and its multipliers
+      if (ok == 1 && s.alpha > s.alpha_target) {   // next continuation level, from this optimum and its multipliers
         for (int i = tid; i < n; i += NT) s.ua[i] = s.uv[i];            // the last accepted answer and its multipliers (the ADMM
         for (int i = tid; i < WG<N>::NL * 5; i += NT) s.ya[i] = s.py[i];   // iterate is not needed any more)
-        if (tid == 0) { s.alpha_ok = s.alpha; s.alpha = fmax(s.alpha * (TV)0.1, alpha_target); }
+        if (tid == 0) { s.alpha_ok = s.alpha; s.alpha = fmax(s.alpha * (TV)0.1, s.alpha_target); }
         wsync<NW>();
         ok = 0; cont_retry = 0;
         kind = R_CONT;
