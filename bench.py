@@ -115,6 +115,22 @@ def gait_breakdown(solver, N, delta, B, steps=5):
         torch.cuda.synchronize()
         st = o["status"].cpu().numpy()
         out[name] = {"qp_per_s": B * steps / (e0.elapsed_time(e1) * 1e-3), "solved_fraction": float(((st == 1) | (st == 2)).mean())}
+    # the same engine on a batch that fills the device many times over (BASELINE config 4's 65 536 QPs on ONE GPU): the rate when
+    # the launch is not as long as its longest QPs
+    big = 65536
+    b = mpcqp.synth.make_batch(big, N, delta, 20250810, ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0))
+    dev = solver.upload(b)
+    for _ in range(2):
+        o = solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        o = solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+    e1.record()
+    torch.cuda.synchronize()
+    st = o["status"].cpu().numpy()
+    out["mixed_batch_65536"] = {"qp_per_s": big * 3 / (e0.elapsed_time(e1) * 1e-3), "solved_fraction": float(((st == 1) | (st == 2)).mean())}
     return out
 
 

@@ -1172,8 +1172,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
     const int max_iter = cfg.max_iter, polish_max = cfg.polish_max;
     int ok = 0;
     const int warm = __builtin_amdgcn_readfirstlane(s.warm);
-    // One loop, three kinds of round, so that the polish and the ADMM block are each inlined exactly once (the kernel's code has
-    // to stay inside the instruction cache that the waves of two CUs share):
+    // One loop, three kinds of round, so that the polish and the ADMM block are each inlined exactly once:
     //   WARM   (warm start only) polish steps on the guess's own active set before any ADMM block
     //   ADMM   an ADMM block, then polish steps; on failure OSQP's rho adaptation and another round until max_iter is spent
     //   CONT   (continuation) the regulariser has just been lowered: polish steps from the previous level's optimum
