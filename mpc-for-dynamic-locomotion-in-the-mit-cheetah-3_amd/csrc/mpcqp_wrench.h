@@ -78,6 +78,21 @@ struct SmemW {
 };
 
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// A wave-uniform float, moved to a scalar register (loop-carried uniform values otherwise occupy a vector register each).
+__device__ __forceinline__ float ufloat(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+// The thread index of a register phase.  One wave per QP: recomputed from the lane counter where it is needed (two VALU
+// instructions, not hoistable, nothing kept alive between phases -- a copy of threadIdx.x held across the fp64 sweep is spilled,
+// and so is every LDS address LLVM derives from it ahead of the round loop).  Four waves: an opaque copy of threadIdx.x.
+template <int NW>
+__device__ __forceinline__ int fresh_tid(int tid0) {
+  if constexpr (NW == 1) {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  } else {
+    return opaque(tid0);
+  }
+}
 
 template <int NW>
 __device__ __forceinline__ void wsync() {
@@ -713,8 +728,8 @@ __device__ __forceinline__ float w_ratio(SmemW<TV, N>& s, const WrTabs& tabs, co
 // The same for the iterate the last ADMM block left in LDS (only needed when its polish steps failed).
 template <typename TV, int N>
 __device__ __forceinline__ float w_ratio_lds(SmemW<TV, N>& s, const WrTabs& tabs, const int tid0) {
-  constexpr int NL = WG<N>::NL;
-  const int tid = opaque(tid0), L = min(tid, NL - 1);
+  constexpr int NL = WG<N>::NL, NW = WG<N>::NW;
+  const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1);
   TV u[3], z[5], y[5], g[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) { u[a] = s.ua[3 * L + a]; g[a] = s.gl[3 * L + a]; }
@@ -744,7 +759,9 @@ __device__ __forceinline__ void w_admm_sys(const SmemW<TV, N>& s, const DevCfg& 
 #pragma unroll
     for (int a = 0; a < 3; ++a) Ls.A[c][3 + a] = a == c ? (TM)s.cm[L] : (TM)0;
   }
-  const TM r = (TM)rho, m = (TM)s.mu, a2 = (TM)((TV)2 * s.alpha), sigma = (TM)cfg.sigma;
+  TM sigma = (TM)cfg.sigma;
+  if constexpr (sizeof(TM) == 4) sigma = ufloat(sigma);   // (a converted configuration constant is hoisted out of the QP loop: keep it scalar)
+  const TM r = (TM)rho, m = (TM)s.mu, a2 = (TM)((TV)2 * s.alpha);
   Ls.dinv[0] = Ls.dinv[1] = stance ? (TM)1 / (a2 + sigma + (TM)2 * r) : (TM)0;
   Ls.dinv[2] = stance ? (TM)1 / (a2 + sigma + r * ((TM)1 + (TM)4 * m * m)) : (TM)0;
 }
@@ -769,7 +786,7 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
   STAMP_INIT
   for (;;) {
     {   // ---- phase A: E = sum_legs A diag(dinv) A'
-      const int tid = opaque(tid0), L = min(tid, NL - 1);
+      const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1);
       LegSys<TM> Ls;
       w_admm_sys<TV, TM, N>(s, cfg, L, rho, Ls);
       w_build_E<TM, N>(Ls, E, tid);
@@ -777,14 +794,14 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
     STAMP(1);
     WTile<TM> tile;
     {   // ---- phase B: S = K^-1 + E, swept in place
-      const int tid = opaque(tid0), gr = tid / G, gc = tid % G;
+      const int tid = fresh_tid<NW>(tid0), gr = tid / G, gc = tid % G;
       w_tile_init<TM, N>(tile, kinvT, E, gr, gc, tid);
       STAMP(2);
       w_sweep<TM, N>(tile, piv, gr, gc);
     }
     STAMP(3);
     {   // ---- phase C: iterations it .. seg_end from the state in LDS, state back to LDS
-      const int tid = opaque(tid0), L = min(tid, NL - 1), gr = tid / G, gc = tid % G;
+      const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1), gr = tid / G, gc = tid % G;
       const bool leg = tid < NL, stance = s.ct[L] != 0;
       const TM sigma = (TM)cfg.sigma, relax = (TM)cfg.relax, om = (TM)1 - relax, BIG = (TM)1e30, r = (TM)rho;
       if (tid >= WG<N>::NQ && tid < WG<N>::DP) bv[tid] = (TM)0;   // pad slots of the mat-vec input, in THIS phase's element type
@@ -852,7 +869,7 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
     K = min(HARD_ITER_FACTOR * K, cfg.max_iter);
     seg_end = K;
   }
-  if (opaque(tid0) == 0) { s.rho = rho; s.iters += K; s.hard |= hard; }
+  if (fresh_tid<NW>(tid0) == 0) { s.rho = rho; s.iters += K; s.hard |= hard; }
   wsync<NW>();
 }
 
@@ -911,7 +928,7 @@ __device__ __forceinline__ int w_polish(SmemW<TV, N>& s, const WrTabs& tabs, con
   TP* const cv = reinterpret_cast<TP*>(s.cv);
   STAMP_INIT
   {   // ---- phase A: active-set rule on (pu, py): rows 0 fz | 1 fx - mu fz <= 0 | 2 fx + mu fz >= 0 | 3,4 same for fy
-    const int tid = opaque(tid0), L = min(tid, NL - 1);
+    const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1);
     const bool stance = s.ct[L] != 0;
     const TV muv = s.mu, fminv = s.fmin, fmaxv = s.fmax;
     int zs = 0, xs = 0, ys = 0;
@@ -937,38 +954,34 @@ __device__ __forceinline__ int w_polish(SmemW<TV, N>& s, const WrTabs& tabs, con
   STAMP(9);
   WTile<TP> tile;
   {   // ---- phase B: S = K^-1 + E, swept in place
-    const int tid = opaque(tid0), gr = tid / G, gc = tid % G;
+    const int tid = fresh_tid<NW>(tid0), gr = tid / G, gc = tid % G;
     w_tile_init<TP, N>(tile, kinvT, E, gr, gc, tid);
     STAMP(10);
     w_sweep<TP, N>(tile, piv, gr, gc);
   }
   STAMP(11);
   // ---- phase C: solve in the free variables from the projection of pu, duals, KKT
-  const int tid = opaque(tid0), L = min(tid, NL - 1), gr = tid / G, gc = tid % G;
+  const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1), gr = tid / G, gc = tid % G;
   const bool leg = tid < NL, stance = s.ct[L] != 0;
   if (tid >= WG<N>::NQ && tid < WG<N>::DP) bv[tid] = (TP)0;   // pad slots of the mat-vec input, in this phase's element type
   const ActSet as(s.aset[L], stance);
   const int zs = as.zs, xs = as.xs, ys = as.ys;
   const bool ez = as.ez, ex = as.ex, ey = as.ey;
-  const TV muv = s.mu, fminv = s.fmin, fmaxv = s.fmax;
-  const TV txs = (TV)xs * muv, tys = (TV)ys * muv;
-  const float gmaxf = s.gmax;
-  const float tol_stat = (sizeof(TV) == 8) ? (1e-6f + 1e-9f * gmaxf) : (3e-7f * fmaxf(gmaxf, 1.f));
-  const float acc_stat = (sizeof(TV) == 8) ? (1e-5f + 1e-8f * gmaxf) : (1e-5f * fmaxf(gmaxf, 1.f));
-  const float ftol = (sizeof(TV) == 8) ? 1e-7f : 2e-5f;
-  const float dtol = (sizeof(TV) == 8) ? (1e-5f + 1e-9f * gmaxf) : (2e-5f * fmaxf(1.f, gmaxf));
-  TV up3[3] = {0, 0, 0};
-  if (stance && zs != 0) {
-    const TV F = zs > 0 ? fmaxv : fminv;
-    up3[2] = F; up3[0] = txs * F; up3[1] = tys * F;
+  // (only what the refinement loop needs is read here: the loop carries the fp64 tile, and every extra live value is a spill)
+  TV txs, tys;
+  TV v3[3];   // the reduced variables; where a component is fixed (bound / tied / swing) v3 holds its fixed value instead
+  {
+    const TV muv = s.mu;
+    txs = (TV)xs * muv; tys = (TV)ys * muv;
+    const TV F = zs > 0 ? (TV)s.fmax : (TV)s.fmin;
+    v3[0] = ex ? s.pu[3 * L] : (TV)0; v3[1] = ey ? s.pu[3 * L + 1] : (TV)0;
+    v3[2] = ez ? s.pu[3 * L + 2] : ((stance && zs != 0) ? F : (TV)0);
   }
-  TV v3[3] = {ex ? s.pu[3 * L] : (TV)0, ey ? s.pu[3 * L + 1] : (TV)0, ez ? s.pu[3 * L + 2] : (TV)0};
   TV uc[3], gr3[3] = {0, 0, 0};
   auto expand = [&]() {
-    uc[0] = up3[0]; uc[1] = up3[1]; uc[2] = up3[2];
-    if (ez) { uc[2] = v3[2]; uc[0] = txs * v3[2]; uc[1] = tys * v3[2]; }
-    if (ex) uc[0] = v3[0];
-    if (ey) uc[1] = v3[1];
+    uc[2] = v3[2];
+    uc[0] = ex ? v3[0] : txs * v3[2];
+    uc[1] = ey ? v3[1] : tys * v3[2];
   };
   float stat = INFINITY, prev = INFINITY;
   for (int rf = 0;; ++rf) {
@@ -984,9 +997,11 @@ __device__ __forceinline__ int w_polish(SmemW<TV, N>& s, const WrTabs& tabs, con
                   leg ? fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2])) : 0.f};
     if (!isfinite(q[0])) q[0] = INFINITY;
     wmax<2, NW>(q, s.red, tid);
-    prev = stat; stat = q[0];
+    prev = stat; stat = ufloat(q[0]);
     // refine until the stationarity residual is safely below what the acceptance test will ask for (it scales with 2 alpha:
     // binding for alpha < 1e-2, where one fp64 solve -- residual ~1e-9 |g| -- is not enough)
+    const float gmaxl = s.gmax;
+    const float tol_stat = (sizeof(TV) == 8) ? (1e-6f + 1e-9f * gmaxl) : (3e-7f * fmaxf(gmaxl, 1.f));
     const float tol = fminf(tol_stat, 0.25f * ((sizeof(TV) == 8) ? 2.f * (float)s.alpha : 1e30f) * 2e-5f * fmaxf(1.f, q[1]));
     if (stat <= tol || rf >= 4 || (rf > 0 && !(stat < 0.5f * prev))) break;   // converged / stagnated (uniform)
     const TP rhs[3] = {(TP)(-rg[0]), (TP)(-rg[1]), (TP)(-rg[2])};
@@ -999,6 +1014,11 @@ __device__ __forceinline__ int w_polish(SmemW<TV, N>& s, const WrTabs& tabs, con
     v3[0] += ex ? (TV)dx[0] : (TV)0; v3[1] += ey ? (TV)dx[1] : (TV)0; v3[2] += ez ? (TV)dx[2] : (TV)0;
   }
   // duals from stationarity grad_leg + G_A' y_A = 0, then primal feasibility + dual sign
+  const TV muv = s.mu, fminv = s.fmin, fmaxv = s.fmax;
+  const float gmaxf = s.gmax;
+  const float acc_stat = (sizeof(TV) == 8) ? (1e-5f + 1e-8f * gmaxf) : (1e-5f * fmaxf(gmaxf, 1.f));
+  const float ftol = (sizeof(TV) == 8) ? 1e-7f : 2e-5f;
+  const float dtol = (sizeof(TV) == 8) ? (1e-5f + 1e-9f * gmaxf) : (2e-5f * fmaxf(1.f, gmaxf));
   TV yn[5] = {0, 0, 0, 0, 0};
   float viol[3] = {0.f, 0.f, 0.f};
   if (leg && stance) {
@@ -1113,9 +1133,8 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
     // The lane index is made opaque once per QP: everything derived from it (addresses into the constant tables, role
     // masks, loop coefficients) is invariant across the QPs of a resident wave, and LLVM would hoist all of it out of
     // this loop -- several hundred registers' worth, spilled for the whole kernel.
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int gr = tid / G, gc = tid % G;
+    const int tid0 = threadIdx.x;
+    int tid = fresh_tid<NW>(tid0);
     size_t b = blockIdx.x;
     if (ob.list) {
       if (tid == 0) s_next = atomicAdd(ob.head, 1);
@@ -1183,7 +1202,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       int budget = kind == R_WARM ? min(warm_tries, polish_max) : 2 * polish_max;
       const bool admm_only = !(cfg.flags & MPCQP_FLAG_POLISH);
       if (kind == R_ADMM) {
-        w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, (round == 0 && warm >= 2) ? WARM_K : 0, tid);
+        w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, (round == 0 && warm >= 2) ? WARM_K : 0, tid0);
         budget = admm_only ? 0 : (__builtin_amdgcn_readfirstlane(s.hard) ? HARD_POLISH_FACTOR : 1) * polish_max;
       }
       // Active-set steps while they make progress: a step that does not at least halve the KKT violation of the previous one
@@ -1192,12 +1211,13 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       const bool last = kind != R_ADMM || __builtin_amdgcn_readfirstlane(s.iters) >= max_iter;   // (a round that nothing follows keeps its full budget)
       float vprev = INFINITY;
       for (int ps = 0; ps < budget && !ok; ++ps) {
-        ok = __builtin_amdgcn_readfirstlane(w_polish<TV, TP, N>(s, tabs, kinvP, tid));
-        const float v = s.kkt[1] + s.kkt[2] / fmaxf(s.gmax, 1.f) * 100.f;
+        ok = __builtin_amdgcn_readfirstlane(w_polish<TV, TP, N>(s, tabs, kinvP, tid0));
+        const float v = ufloat(s.kkt[1] + s.kkt[2] / fmaxf(s.gmax, 1.f) * 100.f);
         if (!ok && ps >= POLISH_PATIENCE && !(v < 0.5f * vprev) && !last) break;   // uniform
         vprev = v;
       }
       if (ok == 1 && s.alpha > s.alpha_target) {   // next continuation level, from this optimum and its multipliers
+        const int tid = fresh_tid<NW>(tid0);
         for (int i = tid; i < n; i += NT) s.ua[i] = s.uv[i];            // the last accepted answer and its multipliers (the ADMM
         for (int i = tid; i < WG<N>::NL * 5; i += NT) s.ya[i] = s.py[i];   // iterate is not needed any more)
         if (tid == 0) { s.alpha_ok = s.alpha; s.alpha = fmax(s.alpha * (TV)0.1, s.alpha_target); }
@@ -1209,6 +1229,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       if (ok) break;
       if (kind == R_CONT) {   // level not reached: back to the last accepted point and a smaller step (geometric bisection), a few times
         if (++cont_retry > 3) { ok = 3; break; }                         // ... then the previous level's answer, status MAX_ITER
+        const int tid = fresh_tid<NW>(tid0);
         for (int i = tid; i < n; i += NT) s.pu[i] = s.ua[i];
         for (int i = tid; i < WG<N>::NL * 5; i += NT) s.py[i] = s.ya[i];
         if (tid == 0) s.alpha = sqrt(s.alpha_ok * s.alpha);
@@ -1219,7 +1240,8 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       if (!admm_only && s.iters >= max_iter) break;
       {   // residuals of the last ADMM iterate: OSQP's termination test (ADMM only -- what the reference runs, polish off,
           // src/mpc.py:51-55) and its rho adaptation for the next block
-        const float ratio = w_ratio_lds<TV, N>(s, tabs, tid);
+        const float ratio = w_ratio_lds<TV, N>(s, tabs, tid0);
+        const int tid = fresh_tid<NW>(tid0);
         wsync<NW>();
         if (admm_only) {
           const float tp = (float)cfg.eps_abs + (float)cfg.eps_rel * s.resid[2], td = (float)cfg.eps_abs + (float)cfg.eps_rel * s.resid[3];
@@ -1236,7 +1258,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       }
       ++round;
     }
-    w_output<TV, TIO, N>(s, tabs, ug, Xg, statusg, itersg, resg, in.y_state, b, ok, tid);
+    w_output<TV, TIO, N>(s, tabs, ug, Xg, statusg, itersg, resg, in.y_state, b, ok, fresh_tid<NW>(tid0));
 #ifdef MPCQP_STAMPS
     if (tid == 0 && b < 65536) {
       unsigned hw, xcc;

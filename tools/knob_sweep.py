@@ -14,7 +14,7 @@ CES = tuple(int(x) for x in os.environ.get('KNOB_CE', '40,50,60,80,100,130').spl
 RHOS = tuple(float(x) for x in os.environ.get('KNOB_RHO', '1.0,2.0').split(','))
 PMS = tuple(int(x) for x in os.environ.get('KNOB_PM', '3,4').split(','))
 for ce, rho, pm in itertools.product(CES, RHOS, PMS):
-    sol = mpcqp.MPCBatch(N=10, precision="mixed", check_every=ce, max_iter=4 * ce, rho=rho, polish_max=pm)
+    sol = mpcqp.MPCBatch(N=10, precision="mixed", check_every=ce, max_iter=int(os.environ.get("KNOB_MIF", "4")) * ce, rho=rho, polish_max=pm)
     dev = sol.upload(batch)
     for _ in range(2):
         out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
