@@ -488,6 +488,11 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   d.flags = cfg->flags;
   d.alpha_floor = ALPHA_FLOOR;
   if (const char* ev = getenv("MPCQP_ALPHA_FLOOR")) { const double v = atof(ev); if (v > 0) d.alpha_floor = v; }   // developer knob
+  // Early rho check (wrench engine): the ratio beyond which a QP is given a larger penalty and a longer block.  The all-fp64 ADMM
+  // sees a clean dual residual and larger ratios than the fp32-tile one, whose dual residual carries the solve's rounding noise;
+  // chosen on batches of other seeds than the bench's (tools/adapt_sweep.py).
+  d.adapt_thr = cfg->precision == MPCQP_PREC_F64 ? 15.f : (cfg->N > 10 ? 10.f : 6.f);
+  if (const char* ev = getenv("MPCQP_ADAPT_THR")) { const double v = atof(ev); if (v > 0) d.adapt_thr = (float)v; }     // developer knob
 
   // coefficient tables: c0[j][j'] = delta^2 (N - max(j,j')),
   // c1[j][j'] = delta^4 sum_{k > max(j,j')}^{N} (k-1-j+theta)(k-1-j'+theta)

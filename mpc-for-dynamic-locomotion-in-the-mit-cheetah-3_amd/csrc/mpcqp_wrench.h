@@ -774,6 +774,10 @@ template <typename TV, typename TM, int N>
 __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const WrTabs& tabs, const TM* __restrict__ kinvT, const int adapt,
                                        const int kfirst, const int tid0) {
   constexpr int NL = WG<N>::NL, NW = WG<N>::NW, G = WG<N>::G;
+  // Element type of the sweep that inverts S.  Horizon 20: fp64 even when the iterations run on an fp32 tile -- the fp32 sweep of
+  // the 120 x 120 system leaves the ADMM iterate ~5e-4 off (10 x the horizon-10 figure) and the active set of 0.2 - 0.8 % of the
+  // low-friction QPs never settles; rounding the fp64 inverse to fp32 costs 13 % and leaves 1 - 3 of 4096 (tools/adapt_sweep.py).
+  using TS = std::conditional_t<(N > 10), double, TM>;
   TM* const E = reinterpret_cast<TM*>(s.E);
   TM* const piv = reinterpret_cast<TM*>(s.piv);
   TM* const bv = reinterpret_cast<TM*>(s.bv);
@@ -787,17 +791,29 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
   for (;;) {
     {   // ---- phase A: E = sum_legs A diag(dinv) A'
       const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1);
-      LegSys<TM> Ls;
-      w_admm_sys<TV, TM, N>(s, cfg, L, rho, Ls);
-      w_build_E<TM, N>(Ls, E, tid);
+      LegSys<TS> Ls;
+      w_admm_sys<TV, TS, N>(s, cfg, L, rho, Ls);
+      w_build_E<TS, N>(Ls, reinterpret_cast<TS*>(s.E), tid);
     }
     STAMP(1);
     WTile<TM> tile;
     {   // ---- phase B: S = K^-1 + E, swept in place
       const int tid = fresh_tid<NW>(tid0), gr = tid / G, gc = tid % G;
-      w_tile_init<TM, N>(tile, kinvT, E, gr, gc, tid);
-      STAMP(2);
-      w_sweep<TM, N>(tile, piv, gr, gc);
+      if constexpr (sizeof(TS) == sizeof(TM)) {
+        w_tile_init<TM, N>(tile, kinvT, E, gr, gc, tid);
+        STAMP(2);
+        w_sweep<TM, N>(tile, piv, gr, gc);
+      } else {   // swept in fp64, rounded to the fp32 tile the iterations use
+        WTile<TS> t64;
+        w_tile_init<TS, N>(t64, tabs.kinv64, reinterpret_cast<const TS*>(s.E), gr, gc, tid);
+        STAMP(2);
+        w_sweep<TS, N>(t64, reinterpret_cast<TS*>(s.piv), gr, gc);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tile.v[i][j] = mk2((float)t64.v[i][2 * j], (float)t64.v[i][2 * j + 1]);
+        }
+      }
     }
     STAMP(3);
     {   // ---- phase C: iterations it .. seg_end from the state in LDS, state back to LDS
@@ -852,7 +868,7 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
           ratio = w_ratio<TV, N>(s, tabs, u3, z5, y5, g3, (TV)A.mu, leg, tid);
         }
         STAMP(5);
-        if (ratio > ADAPT_THR) { rebuild = true; break; }        // uniform: slowly converging QP -> larger penalty, rebuilt matrix
+        if (ratio > cfg.adapt_thr) { rebuild = true; break; }        // uniform: slowly converging QP -> larger penalty, rebuilt matrix
         seg_end = K;
       }
       if (leg) {
