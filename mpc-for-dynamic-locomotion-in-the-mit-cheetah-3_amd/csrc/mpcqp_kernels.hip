@@ -362,46 +362,32 @@ static bool invert_small(int n, const double* A, double* Ai) {
   return ok;
 }
 
-// Tables of the wrench-space engine (mpcqp_wrench.h): K_q = 2 (wP_q c1 + wQ_q c0) and its inverse, the latter laid out as
-// the 8 x 8 register tiles of the G x G lane grid.  Returns false when the configuration does not admit the form.
+// Tables of the wrench-space engine (mpcqp_wrench.h): K_q = 2 (wP_q c1 + wQ_q c0) and its inverse per wrench component, the
+// latter in fp64 and rounded to fp32.  Returns false when the configuration does not admit the form.
 template <int N>
 static bool build_wrench_tables(mpcqp_engine* e, const double* tab /* c0 | c1 */) {
   const MpcQpConfig& c = e->cfg;
   if (c.w[6] != c.w[7]) return false;                       // omega weight must be isotropic in x, y (K block diagonal in q)
   for (int i = 6; i < 12; ++i) if (!(c.w[i] > 0)) return false;   // K_q positive definite
-  constexpr int NT = WG<N>::NT, G = WG<N>::G, NQ = WG<N>::NQ;
   double* K = new (std::nothrow) double[6 * N * N];
   double* Ki = new (std::nothrow) double[6 * N * N];
-  float* t32 = new (std::nothrow) float[64 * NT];
-  double* t64 = new (std::nothrow) double[64 * NT];
-  bool ok = K && Ki && t32 && t64;
+  float* Ki32 = new (std::nothrow) float[6 * N * N];
+  bool ok = K && Ki && Ki32;
   for (int q = 0; q < 6 && ok; ++q) {
     for (int i = 0; i < N * N; ++i) K[q * N * N + i] = 2.0 * (c.w[q] * tab[N * N + i] + c.w[6 + q] * tab[i]);
     ok = invert_small(N, K + q * N * N, Ki + q * N * N);
   }
   if (ok) {
-    for (int tid = 0; tid < NT; ++tid) {
-      const int gr = tid / G, gc = tid % G;
-      for (int r = 0; r < 8; ++r)
-        for (int cc = 0; cc < 8; ++cc) {
-          const int R = 8 * gr + r, C = 8 * gc + cc;
-          double v = 0.0;
-          if (R < NQ && C < NQ && R % 6 == C % 6) v = Ki[(R % 6) * N * N + (R / 6) * N + (C / 6)];
-          if (R >= NQ && R == C) v = 1.0;   // identity on the padding: the sweep pivots on all 8 G rows
-          // [16-byte group][lane][element]: fp32 groups of 4 (row r, columns 4 h ..), fp64 groups of 2 (row r, columns 2 h ..)
-          t64[((size_t)(4 * r + cc / 2) * NT + tid) * 2 + cc % 2] = v;
-          t32[((size_t)(2 * r + cc / 4) * NT + tid) * 4 + cc % 4] = (float)v;
-        }
-    }
+    for (int i = 0; i < 6 * N * N; ++i) Ki32[i] = (float)Ki[i];
     hipError_t he = hipMalloc((void**)&e->wr_K, sizeof(double) * 6 * N * N);
     if (he == hipSuccess) he = hipMemcpy(e->wr_K, K, sizeof(double) * 6 * N * N, hipMemcpyHostToDevice);
-    if (he == hipSuccess) he = hipMalloc((void**)&e->wr_kinv32, sizeof(float) * 64 * NT);
-    if (he == hipSuccess) he = hipMemcpy(e->wr_kinv32, t32, sizeof(float) * 64 * NT, hipMemcpyHostToDevice);
-    if (he == hipSuccess) he = hipMalloc((void**)&e->wr_kinv64, sizeof(double) * 64 * NT);
-    if (he == hipSuccess) he = hipMemcpy(e->wr_kinv64, t64, sizeof(double) * 64 * NT, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMalloc((void**)&e->wr_kinv32, sizeof(float) * 6 * N * N);
+    if (he == hipSuccess) he = hipMemcpy(e->wr_kinv32, Ki32, sizeof(float) * 6 * N * N, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMalloc((void**)&e->wr_kinv64, sizeof(double) * 6 * N * N);
+    if (he == hipSuccess) he = hipMemcpy(e->wr_kinv64, Ki, sizeof(double) * 6 * N * N, hipMemcpyHostToDevice);
     if (he != hipSuccess) { (void)hipGetLastError(); ok = false; }
   }
-  delete[] K; delete[] Ki; delete[] t32; delete[] t64;
+  delete[] K; delete[] Ki; delete[] Ki32;
   return ok;
 }
 

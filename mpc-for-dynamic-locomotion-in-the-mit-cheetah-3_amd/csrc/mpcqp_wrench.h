@@ -37,8 +37,8 @@ struct WG {
 // Constant tables of a configuration (device memory, built by mpcqp_create).
 struct WrTabs {
   const double* K;        // [6][N][N]   K_q
-  const float* kinv32;    // [64][NT]    K^-1 in tile layout: element (r, c) of lane tid at [(8 r + c) * NT + tid]
-  const double* kinv64;   // [64][NT]
+  const float* kinv32;    // [6][N][N]   K_q^-1 (w_tile_init gathers the tile entries from it)
+  const double* kinv64;   // [6][N][N]
 };
 
 template <typename TV, int N>
@@ -228,30 +228,43 @@ __device__ __forceinline__ void tilemv(const WTile<double>& t, const double (&x)
   }
 }
 
-// tile <- K^-1 (constant, tile layout in global memory) + E (block diagonal, 6 x 6 per stage, in LDS).
-// Pass 1 loads the lane's 64 K^-1 entries straight into the tile registers as 16-byte coalesced loads, all in flight at once
-// (layout [16 B group][lane]: fp32 group g = row g / 2, columns 4 (g % 2) ..; fp64 group g = row g / 4, columns 2 (g % 4) ..).
+// tile <- K^-1 (constant of the configuration) + E (block diagonal, 6 x 6 per stage, in LDS).
+// K^-1 = (+)_q K_q^-1 couples only equal wrench components: entry (R, C) of the stage-major ordering (index 6 j + q) is
+// kq[q][j][j'] when R = C (mod 6) and zero otherwise, so a lane's 8 x 8 tile holds one such entry per row, or two when the
+// first falls in tile column 0 or 1 (the second is six columns on).  Pass 1 gathers these <= 16 values from the compact
+// table kq (6 N^2 entries: 2.4 / 4.8 KB at horizon 10, resident in the CU's vector L1) and places them by column selects --
+// a full tile-layout table (16 / 32 KB per load, every lane 16 x 16 B) misses L1 for every wave of the CU and its loads
+// queued for ~30 k cycles at full occupancy (the miss queue of the L1, not bandwidth: phase stamps).
 // Pass 2 adds E: entry (R, C) of stage j = R / 6 sits at E[6 R + C - 6 j] and exists iff 0 <= C - 6 j < 6, i.e. for tile
 // column c iff (c - lo) <u 6 with lo = 6 j - 8 gc per tile row; reads outside a row's run are masked (LDS reads never fault).
 template <typename TM, int N>
-__device__ __forceinline__ void w_tile_init(WTile<TM>& t, const TM* __restrict__ kinvT, const TM* __restrict__ E, int gr, int gc, int tid) {
+__device__ __forceinline__ void w_tile_init(WTile<TM>& t, const TM* __restrict__ kq, const TM* __restrict__ E, int gr, int gc, int tid) {
   constexpr int NT = WG<N>::NT, NQ = WG<N>::NQ;
   asm volatile("" : "+v"(gr), "+v"(gc), "+v"(tid));   // (opaque: keeps the per-lane index arithmetic out of the enclosing loops' preheaders)
-  if constexpr (sizeof(TM) == 4) {
-    const float4* k4 = reinterpret_cast<const float4*>(kinvT);
+  TM v0[8], v1[8];
+  int c0[8];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const float4 v = k4[(size_t)g * NT + tid];
-      t.v[g / 2][2 * (g % 2)] = mk2(v.x, v.y);
-      t.v[g / 2][2 * (g % 2) + 1] = mk2(v.z, v.w);
-    }
-  } else {
-    const double2* k2 = reinterpret_cast<const double2*>(kinvT);
+  for (int r = 0; r < 8; ++r) {
+    const int R = 8 * gr + r, jR = (R * 43) >> 8, qR = R - 6 * jR;   // R / 6 for R < 128
+    const int d = R - 8 * gc;                                          // tile column of the diagonal (any sign)
+    const int dm = d + 126, m = dm - 6 * ((dm * 171) >> 10);           // d mod 6 in [0, 6): x / 6 = (171 x) >> 10 for x < 500
+    const int C0 = 8 * gc + m, j0 = (C0 * 43) >> 8;
+    const bool rowok = R < NQ, ok0 = rowok && C0 < NQ, ok1 = rowok && m < 2 && C0 + 6 < NQ;
+    const TM* row = kq + (qR * N + min(jR, N - 1)) * N;
+    v0[r] = row[ok0 ? j0 : 0];
+    v1[r] = row[ok1 ? j0 + 1 : 0];
+    if (!ok0) v0[r] = (TM)0;
+    if (!ok1) v1[r] = (TM)0;
+    c0[r] = m;
+    if (!rowok) { v0[r] = (TM)1; c0[r] = (d >= 0 && d < 8) ? d : 8; }   // identity on the padding: the sweep pivots on all 8 G rows
+  }
 #pragma unroll
-    for (int g = 0; g < 32; ++g) {
-      const double2 v = k2[(size_t)g * NT + tid];
-      t.v[g / 4][2 * (g % 4)] = v.x;
-      t.v[g / 4][2 * (g % 4) + 1] = v.y;
+  for (int r = 0; r < 8; ++r) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      TM v = c == c0[r] ? v0[r] : (TM)0;
+      if (c >= 6) v = c == c0[r] + 6 ? v1[r] : v;
+      tset(t, r, c, v);
     }
   }
 #pragma unroll

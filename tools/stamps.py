@@ -18,7 +18,7 @@ names = ["setup-rest", "matrix-desc", "build", "sweep", "admm-iters", "checkpoin
          "-", "-", "-", "-", "setup-load", "setup-model+g"]
 if os.environ.get("MPCQP_STAMP_NAMES", "wrench") == "wrench" and N == 10 and prec != "f32":
     names = ["setup", "admm-E", "admm-tile-init", "admm-sweep", "admm-iters", "rho-check", "polish-solve+kkt", "polish-publish", "output",
-             "polish-E", "polish-tile-init", "polish-sweep", "-", "-", "-"]
+             "polish-E", "polish-tile-init", "polish-sweep", "table-wait(in tile-init)", "-", "-"]
 buf = (ctypes.c_ulonglong * 32)()
 for rep in range(2):
     sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
