@@ -59,7 +59,7 @@ def test_config5_full_size_properties():
     b = mpcqp.synth.config5(4096)
     out = gpu_solve(b, N=20, io="f32", precision="mixed")
     ok = _check_properties(b, out, 20)
-    assert ok.mean() >= 0.995, ok.mean()
+    assert ok.mean() >= 0.999, ok.mean()      # (the ADMM block inverts S in fp64 at this horizon: 99.98 % measured, 99.78 % before)
     out2 = gpu_solve(b, N=20, io="f32", precision="mixed")
     assert np.array_equal(out["u"], out2["u"]) and np.array_equal(out["status"], out2["status"])
     cfg = S.QPConfig(N=20, delta=0.03, alpha=1e-2)
@@ -74,9 +74,33 @@ def test_config5_precisions_against_oracle(oracle_solve, precision):
     ref = oracle_solve(b, N=20)
     out = gpu_solve(b, N=20, io="f64", precision=precision)
     ok = solved(out["status"])
-    assert ok.mean() >= 0.98
+    assert ok.mean() >= 0.99
     assert rel_err(out["u"], ref["u"])[ok].max() <= 1e-4
     assert np.abs(out["X"][ok] - ref["X"][ok]).max() <= 1e-4
+
+
+def test_config5_f64_full_size_all_solved():
+    b = mpcqp.synth.config5(4096)
+    out = gpu_solve(b, N=20, io="f32", precision="f64")
+    ok = _check_properties(b, out, 20)
+    assert ok.mean() >= 0.9995, ok.mean()     # 100 % measured
+
+
+@pytest.mark.parametrize("N", [10, 20])
+def test_admm_iterate_is_the_oracles_osqp_iterate(oracle_lib, N):
+    """Polish off, tolerances 0, exactly K <= 25 iterations (no rho adaptation inside): the all-fp64 engine must return the
+    iterate of the oracle's OSQP loop (oracle/mpcqp_oracle.c: same rho / sigma / relaxation, dense Cholesky solves) to rounding
+    -- the two share no linear algebra -- and the fp32-tile engine the same iterate to its solve accuracy."""
+    b = mpcqp.synth.config3(128) if N == 10 else mpcqp.synth.config5(128)
+    for K in (3, 25):
+        kw = dict(flags=0, eps_abs=0.0, eps_rel=0.0, max_iter=K, check_every=K)
+        cfg = oracle_lib.default_config(N=N, delta=0.03, **kw)
+        ref = mpcqp.Engine(oracle_lib, cfg).solve_batch_host(b["x0"], b["r"], b["contact"], b["xdes"], b["mu"])
+        assert np.all(ref["iters"] % 1000 == K)
+        for precision, tol in (("f64", 1e-9), ("mixed", 2e-3 if N == 10 else 1e-2)):
+            out = gpu_solve(b, N=N, io="f64", precision=precision, **kw)
+            assert np.all(out["iters"] % 1000 == K) and np.all((out["status"] == 3) | (out["status"] == 2))   # (2: a QP whose residuals are exactly 0)
+            assert rel_err(out["u"], ref["u"]).max() <= tol, (N, K, precision, rel_err(out["u"], ref["u"]).max())
 
 
 @pytest.mark.parametrize("N,precision", [(10, "mixed"), (10, "f64"), (20, "mixed"), (20, "f64")])
