@@ -1242,6 +1242,12 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       for (int ps = 0; ps < budget && !ok; ++ps) {
         ok = __builtin_amdgcn_readfirstlane(w_polish<TV, TP, N>(s, tabs, kinvP, tid0));
         const float v = ufloat(s.kkt[1] + s.kkt[2] / fmaxf(s.gmax, 1.f) * 100.f);
+#if defined(MPCQP_STAMPS)   // (diagnostic build, single-QP launches: a trace of the polish steps, tools/hardest.py)
+        if (Btot == 1 && fresh_tid<NW>(tid0) == 0 && s.psteps <= 80) {
+          double* rec = g_wdbg + 1300 + 8 * (s.psteps - 1);
+          rec[0] = kind * 100 + round; rec[1] = ps; rec[2] = s.kkt[0]; rec[3] = s.kkt[1]; rec[4] = s.kkt[2]; rec[5] = s.rho; rec[6] = s.iters; rec[7] = ok;
+        }
+#endif
         if (!ok && ps >= POLISH_PATIENCE && !(v < 0.5f * vprev) && !last) break;   // uniform
         vprev = v;
       }

@@ -33,3 +33,10 @@ for which, L in (("product", None), ("stamps", lib)):
             v = np.array(list(buf), dtype=np.float64)
             line += "  cycles: " + ", ".join(f"{n} {v[i]:.0f} ({v[16 + i]:.0f}x)" for i, n in enumerate(names) if v[i] > 0)
         print(line, flush=True)
+        if L is not None:
+            dbg = (ctypes.c_double * 2048)()
+            if L.lib.mpcqp_debug_read_wdbg(dbg) == 0:
+                d = np.array(list(dbg))[1300:1300 + 8 * 80].reshape(80, 8)
+                nst = int(o1["iters"][0]) // 1000
+                for r in d[:nst]:
+                    print(f"      kind/round {int(r[0]):3d} step {int(r[1])} stat {r[2]:.2e} prim {r[3]:.2e} dual {r[4]:.2e} rho {r[5]:.3g} iters {int(r[6])} ok {int(r[7])}")
