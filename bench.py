@@ -161,7 +161,9 @@ def main():
     torch.cuda.set_device(device_index)
     dist = None
     backend = os.environ.get("MPCQP_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" for 1-GPU rehearsals
-    if world > 1:
+    # (MPCQP_BENCH_DIST1=1 under `torch.distributed.run --nproc-per-node 1`: the process-group branch with one rank -- how the
+    #  RCCL calls below are rehearsed on a one-GPU box, tests/test_gpu_configs45.py)
+    if world > 1 or os.environ.get("MPCQP_BENCH_DIST1") == "1":
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -177,7 +179,7 @@ def main():
     solver = mpcqp.MPCBatch(N=N, delta=delta, device=device_index, io_dtype="f32", precision=args.precision)
     dev = solver.upload(batch)
     gathered = None
-    if args.allgather and world > 1:   # RCCL: device buffers over xGMI; gloo (1-GPU rehearsals): through host memory
+    if args.allgather and dist is not None:   # RCCL: device buffers over xGMI; gloo (1-GPU rehearsals): through host memory
         gathered = torch.empty((world * B, 12), dtype=torch.float32, device=solver.device if backend == "nccl" else "cpu")
 
     def step():

@@ -14,6 +14,7 @@ for p in (REPO, os.path.join(REPO, "oracle")):
 
 
 _BENCH2 = {"proc": None, "result": None}
+_BENCH1N = {"proc": None, "result": None}
 
 
 def pytest_configure(config):
@@ -33,6 +34,13 @@ def pytest_configure(config):
                 [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                  "--master-port", "29517", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--allgather",
                  "--no-cpu-baseline", "--no-breakdown"], cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+            # ... and the RCCL ("nccl") branch of the same script with a single rank: process group on the device, barrier,
+            # all-reduce and all-gather of device tensors -- every collective call the 8-GPU run makes.
+            env1 = dict(os.environ, MPCQP_BENCH_BACKEND="nccl", MPCQP_BENCH_DIST1="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+            _BENCH1N["proc"] = subprocess.Popen(
+                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                 "--master-port", "29518", os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--allgather",
+                 "--no-cpu-baseline", "--no-breakdown"], cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env1)
 
 
 def bench2_result():
@@ -48,6 +56,21 @@ def bench2_result():
             out, err = p.communicate()
         _BENCH2["result"] = (p.returncode, out, err)
     return _BENCH2["result"]
+
+
+def bench1_nccl_result():
+    """(returncode, stdout, stderr) of the one-rank RCCL bench child started in pytest_configure."""
+    if _BENCH1N["result"] is None:
+        p = _BENCH1N["proc"]
+        if p is None:
+            pytest.skip("one-rank RCCL bench child was not started (no GPU at configure time)")
+        try:
+            out, err = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, err = p.communicate()
+        _BENCH1N["result"] = (p.returncode, out, err)
+    return _BENCH1N["result"]
 
 
 def _have_gpu():

@@ -149,3 +149,16 @@ def test_two_rank_bench_rehearsal():
     # whole-job value = units all ranks processed / max-over-ranks time
     assert abs(j["value"] - 2 * 4096 * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]
     assert j["config"]["solved_fraction"] >= 0.99 and "roofline" in j and "cpu_baseline" not in j
+
+
+def test_one_rank_rccl_bench_rehearsal():
+    """The RCCL branch of bench.py (backend "nccl": device-side process group, barrier, all-reduce, all-gather into a device
+    tensor) with one rank on this box's GPU -- the calls the driver's 2/4/8-GPU runs make, which no one-GPU box can run at size."""
+    from conftest import bench1_nccl_result
+    rc, stdout, stderr = bench1_nccl_result()
+    assert rc == 0, stderr[-2000:]
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["config"]["allgather"] is True and j["config"]["solved_fraction"] >= 0.999
+    assert abs(j["value"] - 4096 * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]
