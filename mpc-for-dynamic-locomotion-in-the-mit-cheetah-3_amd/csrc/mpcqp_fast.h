@@ -899,16 +899,15 @@ __device__ __forceinline__ int cost_class(float nst, float demand_over_mu) {
 // 16 lanes per QP, one stage per lane: the loads of a QP go out together, DPP row reductions take the maximum demand and
 // the stance count, lane 0 files the QP.  The class counters are bumped once per workgroup of 64 QPs (a global atomic
 // per QP on a handful of addresses serialises).
-template <typename TIO>
+template <typename TIO, int N = FG::N>
 __global__ void __launch_bounds__(1024)
 mpcqp_order_kernel(const FastIn<TIO> in, const int B, const OrderBuf ob) {
-  constexpr int N = FG::N;
   __shared__ int lcnt[ORDER_BUCKETS], lbase[ORDER_BUCKETS];
   if (threadIdx.x < ORDER_BUCKETS) lcnt[threadIdx.x] = 0;
   __syncthreads();
-  const int b = blockIdx.x * 64 + (threadIdx.x >> 4), k = threadIdx.x & 15;
+  const int b = blockIdx.x * 64 + (threadIdx.x >> 4), k0 = threadIdx.x & 15;
   float score = 0.f, cnt = 0.f;
-  if (b < B && k < N) {
+  for (int k = k0; k < N && b < B; k += 16) {   // (horizons beyond 16: a lane takes stages k0, k0 + 16, ..)
     float fx[4], fy[4], fz[4]; bool st[4]; int nst = 0;
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
@@ -917,9 +916,10 @@ mpcqp_order_kernel(const FastIn<TIO> in, const int B, const OrderBuf ob) {
       st[l] = in.contact[((size_t)b * N + k) * 4 + l] != 0;
       nst += st[l] ? 1 : 0;
     }
-    score = support_demand(nst, fx, fy, fz, st);
-    if (!isfinite(score)) score = 0.f;
-    cnt = (float)nst;
+    float sc = support_demand(nst, fx, fy, fz, st);
+    if (!isfinite(sc)) sc = 0.f;
+    score = fmaxf(score, sc);
+    cnt += (float)nst;
   }
   score = fmaxf(score, dpp_mov<0xB1>(score));    // max / sum over the row of 16 lanes (all lanes of the wave are active here)
   score = fmaxf(score, dpp_mov<0x4E>(score));
@@ -930,9 +930,9 @@ mpcqp_order_kernel(const FastIn<TIO> in, const int B, const OrderBuf ob) {
   cnt += dpp_mov<0x141>(cnt);
   cnt += dpp_mov<0x140>(cnt);
   int bucket = 0, pos = 0;
-  const bool filer = b < B && k == 0;
+  const bool filer = b < B && k0 == 0;
   if (filer) {
-    bucket = cost_class(cnt, score / fmaxf(fabsf((float)in.mu[b]), 1e-3f));
+    bucket = cost_class(cnt * (10.f / N), score / fmaxf(fabsf((float)in.mu[b]), 1e-3f));
     pos = atomicAdd(&lcnt[bucket], 1);
   }
   __syncthreads();

@@ -237,14 +237,19 @@ hipError_t launch_wrench(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void
                          float* res, hipStream_t s) {
   dim3 grid((unsigned)B);
   OrderBuf ob = {nullptr, nullptr, 0, nullptr};
-  if constexpr (N == 10) {   // (the dispatch-order pre-pass of mpcqp_fast.h reads horizon-10 tuples)
-    const int64_t slots = 4 * (int64_t)e->slots;   // e->slots = 2 per CU
+  {
+    const int64_t slots = (N == 10 ? 4 : 1) * (int64_t)e->slots;   // e->slots = 2 per CU: resident workgroups of the horizon-20 kernel
     if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && slots > 0 && B > slots && e->order_cap >= B) {
       ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 32; ob.cap = e->order_cap;
       hipError_t he = hipMemsetAsync(ob.cnt, 0, 32 * sizeof(int), s);
       if (he != hipSuccess) return he;
-      hipLaunchKernelGGL((mpcqp_order_kernel<TIO>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
-      grid = dim3((unsigned)slots);
+      hipLaunchKernelGGL((mpcqp_order_kernel<TIO, N>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
+      // Up to a few device-fills the hardware's own dispatcher does better with the ordered list than resident workgroups on an
+      // atomic queue (B = 4096: 0.53-0.56 ms against 0.60-0.63, tools/order_study.py): a resident wave stays on the SIMD it
+      // started on, next to whatever partner it was given, while a fresh workgroup goes where there is room.
+      static const int64_t listed_max = getenv("MPCQP_LISTED_MAX") ? atoll(getenv("MPCQP_LISTED_MAX")) : 4;   // developer knob (device-fills)
+      if (B <= listed_max * slots) ob.head = nullptr;
+      else grid = dim3((unsigned)slots);
     }
   }
   const WrTabs tabs = {e->wr_K, e->wr_kinv32, e->wr_kinv64};

@@ -1145,8 +1145,10 @@ __device__ __forceinline__ void w_output(SmemW<TV, N>& s, const WrTabs& tabs, TI
 }
 
 // ----------------------------------------------------------------------------------------------------- the kernel
-// Plain form: blockIdx = QP.  Queued form (ob.list != null): resident workgroups pull QPs dearest-expected-first from
-// the queue the pre-pass of mpcqp_fast.h fills; every wave leaves when the queue index passes Btot.
+// Plain form: blockIdx = QP.  Listed form (ob.list != null, ob.head == null): one workgroup per QP, workgroup k takes the k-th QP
+// of the dearest-expected-first order that the pre-pass of mpcqp_fast.h files; the hardware's dispatcher places the workgroups.
+// Queued form (ob.head != null): only as many workgroups as the device holds, each pulling QPs from the head of that order until
+// it is empty (no workgroup turnover: the form for batches many times the device).
 template <typename TV, typename TM, typename TP, typename TIO, int N>
 __global__ void __launch_bounds__(WG<N>::NT, 2)
 mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const FastIn<TIO> in, TIO* ug, TIO* __restrict__ Xg,
@@ -1166,16 +1168,27 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
     int tid = fresh_tid<NW>(tid0);
     size_t b = blockIdx.x;
     if (ob.list) {
-      if (tid == 0) s_next = atomicAdd(ob.head, 1);
-      __syncthreads();
-      int i = __builtin_amdgcn_readfirstlane(s_next);
-      __syncthreads();
-      if (i >= Btot) break;                  // uniform
-      for (int k = ORDER_BUCKETS - 1; k >= 0; --k) {
-        const int c = ob.cnt[k];
-        if (i < c) { b = (size_t)__builtin_amdgcn_readfirstlane(ob.list[(size_t)k * ob.cap + i]); break; }
-        i -= c;
+      int i = blockIdx.x;                    // listed form: workgroup k takes the k-th QP of the dearest-first order
+      if (ob.head) {                         // queued form: resident workgroups pull from the head of that order
+        if (tid == 0) s_next = atomicAdd(ob.head, 1);
+        __syncthreads();
+        i = __builtin_amdgcn_readfirstlane(s_next);
+        __syncthreads();
       }
+      if (i >= Btot) break;                  // uniform
+      int cnt[ORDER_BUCKETS];                // all class counts in one scalar load, then the search in registers
+#pragma unroll
+      for (int k = 0; k < ORDER_BUCKETS; ++k) cnt[k] = ob.cnt[k];
+      int cls = 0, at = 0;
+      bool found = false;
+#pragma unroll
+      for (int k = ORDER_BUCKETS - 1; k >= 0; --k) {
+        const bool hit = !found && i < cnt[k];
+        if (hit) { cls = k; at = i; }
+        found = found || hit;
+        i -= found ? 0 : cnt[k];
+      }
+      b = (size_t)__builtin_amdgcn_readfirstlane(ob.list[(size_t)cls * ob.cap + at]);
     }
 #ifdef MPCQP_STAMPS
     const unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
@@ -1212,7 +1225,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
         itersg[b] = 0;
         if (resg) { resg[2 * b] = 0.f; resg[2 * b + 1] = 0.f; }
       }
-      if (!ob.list) break;
+      if (!ob.list || !ob.head) break;
       continue;
     }
     if (in.u_init) w_warm_start<TV, TIO, N>(s, tabs, in.u_init + b * n, in.y_state ? in.y_state + b * (WG<N>::NL * 5) : nullptr, in.shift, tid);
@@ -1303,7 +1316,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       g_timeline[3 * b + 2] = ((unsigned long long)xcc << 32) | hw;
     }
 #endif
-    if (!ob.list) break;
+    if (!ob.list || !ob.head) break;
   }
 }
 

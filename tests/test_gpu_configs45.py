@@ -62,6 +62,10 @@ def test_config5_full_size_properties():
     assert ok.mean() >= 0.999, ok.mean()      # (the ADMM block inverts S in fp64 at this horizon: 99.98 % measured, 99.78 % before)
     out2 = gpu_solve(b, N=20, io="f32", precision="mixed")
     assert np.array_equal(out["u"], out2["u"]) and np.array_equal(out["status"], out2["status"])
+    # eight device-fills of four-wave workgroups: the queued form; a slice in the plain form gives the same bits
+    sl = {k: (v[3000:3200] if isinstance(v, np.ndarray) and len(v) == 4096 else v) for k, v in b.items()}
+    plain = gpu_solve(sl, N=20, io="f32", precision="mixed", flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NATURAL_ORDER)
+    assert np.array_equal(plain["u"], out["u"][3000:3200]) and np.array_equal(plain["iters"], out["iters"][3000:3200])
     cfg = S.QPConfig(N=20, delta=0.03, alpha=1e-2)
     for i in range(0, 4096, 1024):
         X = S.predict_states(b["x0"][i], out["u"][i].astype(np.float64).reshape(-1), b["r"][i], b["contact"][i], cfg)

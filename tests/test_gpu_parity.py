@@ -295,10 +295,11 @@ def test_regulariser_sweep(oracle_solve, alpha, precision, min_solved):
 
 
 def test_queued_form_matches_plain_form_bitwise():
-    """Batches that oversubscribe the device run in the queued form (resident workgroups pulling QPs
-    dearest-expected-first).  It must be a pure re-ordering: outputs bitwise those of the plain
-    one-workgroup-per-QP form (MPCQP_FLAG_NATURAL_ORDER), non-finite QPs included, for both entry points."""
-    B = 1100                                                   # oversubscribed: 2 workgroup slots per CU on 256 CUs
+    """Batches that oversubscribe the device are dispatched dearest-expected-first: up to four device-fills
+    as one workgroup per QP taking its QP from the ordered list (this size), beyond that as resident workgroups pulling from a
+    queue (tests/test_gpu_configs45.py, B = 65 536).  Either must be a pure re-ordering: outputs bitwise those of the plain
+    blockIdx = QP form (MPCQP_FLAG_NATURAL_ORDER), non-finite QPs included, for both entry points."""
+    B = 2500                                                   # oversubscribed: 8 one-wave workgroups per CU on 256 CUs
     b = mpcqp.synth.config3(B)
     b["x0"] = b["x0"].copy()
     b["x0"][[5, 700, 1099], 3] = np.nan                        # non-finite inputs: status -1, zero outputs, the queue moves on
