@@ -1251,7 +1251,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       // (primal + dual-sign, each relative to its scale) means ADMM has not settled the active set yet -- back to ADMM rather
       // than through the rest of the budget (each step costs an fp64 sweep, about 50 ADMM iterations).
       const bool last = kind != R_ADMM || __builtin_amdgcn_readfirstlane(s.iters) >= max_iter;   // (a round that nothing follows keeps its full budget)
-      float vprev = INFINITY;
+      float vprev = INFINITY, vprev2 = INFINITY;
       for (int ps = 0; ps < budget && !ok; ++ps) {
         ok = __builtin_amdgcn_readfirstlane(w_polish<TV, TP, N>(s, tabs, kinvP, tid0));
         const float v = ufloat(s.kkt[1] + s.kkt[2] / fmaxf(s.gmax, 1.f) * 100.f);
@@ -1261,8 +1261,17 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
           rec[0] = kind * 100 + round; rec[1] = ps; rec[2] = s.kkt[0]; rec[3] = s.kkt[1]; rec[4] = s.kkt[2]; rec[5] = s.rho; rec[6] = s.iters; rec[7] = ok;
         }
 #endif
-        if (!ok && ps >= POLISH_PATIENCE && !(v < 0.5f * vprev) && !last) break;   // uniform
-        vprev = v;
+        {
+          // ... except that the candidates of a converging sequence often ALTERNATE between a primal-feasible one with a wrong
+          // multiplier sign and a dual-feasible one with a small constraint violation (the hardest QP of the bench batch lost two
+          // ADMM rounds to being cut one step short, tools/hardest.py): such a one-sided candidate is compared with the one two
+          // steps before it, like with like, for up to two extra steps.
+          const bool one_sided = fminf(s.kkt[1], s.kkt[2]) <= 1e-9f;
+          const bool stalled = !(v < 0.5f * vprev);
+          const bool alternating = one_sided && ps >= 2 && ps < 4 && v < 0.5f * vprev2;
+          if (!ok && ps >= POLISH_PATIENCE && stalled && !alternating && !last) break;   // uniform
+        }
+        vprev2 = vprev; vprev = v;
       }
       if (ok == 1 && s.alpha > s.alpha_target) {   // next continuation level, from this optimum and its multipliers
         const int tid = fresh_tid<NW>(tid0);
