@@ -6,7 +6,9 @@ sys.path.insert(0, REPO)
 import mpcqp
 from mpcqp import _capi
 prod = _capi.product() if hasattr(_capi, "product") else None
-batch = mpcqp.synth.config3(4096)
+_seed = os.environ.get("HARD_SEED")
+_gaits = tuple(os.environ.get("HARD_GAITS", "trot,pronk,amble,gallop").split(","))
+batch = mpcqp.synth.config3(4096) if _seed is None else mpcqp.synth.make_batch(4096, 10, 0.03, int(_seed), _gaits, (0.3, 0.5, 0.7, 1.0))
 sol = mpcqp.MPCBatch(N=10, precision="mixed")
 dev = sol.upload(batch)
 o = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"]); torch.cuda.synchronize()
