@@ -77,6 +77,10 @@ extern "C" {
                                         QPs dearest-expected-first from a queue (a pre-pass ranks the support patterns by
                                         friction demand): same per-QP results, shorter launch */
 
+#define MPCQP_FLAG_NO_TIMING 64u     /* product library: do not record the HIP event pair around each solve that mpcqp_last_kernel_ms()
+                                        reads (two extra packets on the stream per call, ~15 us of a 0.46 ms solve of 4096 QPs);
+                                        mpcqp_last_kernel_ms() then returns MPCQP_EINVAL */
+
 /*
  * Problem + solver configuration.  POD, versioned by its leading `size` field (set to sizeof(MpcQpConfig)).
  * mpcqp_default_config() fills the Lite3 constants hard-coded in the reference and the engine defaults.
@@ -205,7 +209,8 @@ int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* x, void
 int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* u, const void* jac, void* tau, void* stream);
 
 /* Duration in milliseconds of the most recent solve_batch's kernel(s), measured with HIP events recorded on
- * `stream` around the launch; blocks until that work has finished.  Oracle: wall time of the call. */
+ * `stream` around the launch (after mpcqp_rollout: around all of its ticks); blocks until that work has finished.
+ * MPCQP_EINVAL when the handle was created with MPCQP_FLAG_NO_TIMING.  Oracle: wall time of the call. */
 int mpcqp_last_kernel_ms(mpcqp_handle h, float* ms);
 
 const char* mpcqp_last_error(mpcqp_handle h);

@@ -21,7 +21,7 @@ STATUS_UNSOLVED, STATUS_SOLVED_POLISHED, STATUS_SOLVED_ADMM, STATUS_MAX_ITER, ST
 DISC_EULER, DISC_ZOH = 0, 1
 DTYPE_F32, DTYPE_F64 = 0, 1
 PREC_F32, PREC_MIXED, PREC_F64 = 0, 1, 2
-FLAG_POLISH, FLAG_WARM_START, FLAG_GENERAL_KERNEL, FLAG_NATURAL_ORDER, FLAG_WARM_SHIFT, FLAG_TILE_KERNEL = 1, 2, 4, 8, 16, 32
+FLAG_POLISH, FLAG_WARM_START, FLAG_GENERAL_KERNEL, FLAG_NATURAL_ORDER, FLAG_WARM_SHIFT, FLAG_TILE_KERNEL, FLAG_NO_TIMING = 1, 2, 4, 8, 16, 32, 64
 
 EXPORTED_SYMBOLS = (
     "mpcqp_version", "mpcqp_default_config", "mpcqp_create", "mpcqp_destroy", "mpcqp_solve_batch",

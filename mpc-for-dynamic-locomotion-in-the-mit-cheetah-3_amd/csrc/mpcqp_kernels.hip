@@ -180,6 +180,7 @@ struct mpcqp_engine {
   float* dual_mem = nullptr;  // warm-started engines: multipliers of the previous solve per batch slot [dual_cap][4 N][5]
   int64_t dual_cap = 0;
   bool timed = false;
+  bool quiet = false;         // inside mpcqp_rollout: the per-tick solves record no events (the roll-out times itself as a whole)
   bool ev0_set = false;       // the gait entry point has already recorded the start event (in front of its expansion kernel)
   char err[512];
 };
@@ -546,7 +547,8 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
   if ((wrench || fast) && reserve_workspace(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_solve_batch: workspace allocation failed");
   float* ys = (warm && (fast || wrench) && B > 0) ? h->dual_mem : nullptr;
   const int shift = (h->cfg.flags & MPCQP_FLAG_WARM_SHIFT) ? 1 : 0;
-  if (!h->ev0_set) he = hipEventRecord(h->ev0, st);
+  const bool timing = !(h->cfg.flags & MPCQP_FLAG_NO_TIMING) && !h->quiet;
+  if (!h->ev0_set && timing) he = hipEventRecord(h->ev0, st);
   h->ev0_set = false;
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
   if (B > 0 && (wrench || fast)) {
@@ -572,9 +574,11 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
                  : launch_prec<float, 20>(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, st);
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
   }
-  he = hipEventRecord(h->ev1, st);
-  if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
-  h->timed = true;
+  if (timing) {
+    he = hipEventRecord(h->ev1, st);
+    if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
+    h->timed = true;
+  }
   return MPCQP_OK;
 }
 
@@ -600,7 +604,7 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
   const int64_t total = B * (int64_t)(N * 12 + (N + 1) * 13);
   const dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t st = (hipStream_t)stream;
-  if (hipEventRecord(h->ev0, st) != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord");
+  if (!(h->cfg.flags & MPCQP_FLAG_NO_TIMING) && hipEventRecord(h->ev0, st) != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord");
   if (h->cfg.dtype == MPCQP_DTYPE_F64) {
     const FastIn<double> in = {(const double*)x0, nullptr, nullptr, nullptr, (const double*)mu, (const double*)ref, (const double*)feet0,
                                (const double*)footholds, gait, feet_id, nullptr, nullptr, 0};
@@ -647,6 +651,9 @@ int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* x, void
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = B * (int64_t)(N * 12 + (N + 1) * 13);
   const dim3 ge((unsigned)((total + 255) / 256)), ga((unsigned)((B + 255) / 256));
+  const bool timing = !(h->cfg.flags & MPCQP_FLAG_NO_TIMING);   // (mpcqp_last_kernel_ms after a roll-out: all T ticks)
+  if (timing && hipEventRecord(h->ev0, st) != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord");
+  struct Quiet { mpcqp_engine* e; explicit Quiet(mpcqp_engine* e_) : e(e_) { e->quiet = true; } ~Quiet() { e->quiet = false; } } quiet(h);
   for (int it = 0; it < T; ++it) {   // 3 launches per tick on the caller's stream, no host synchronisation and no copies in between
     if (el == 8)
       hipLaunchKernelGGL((mpcqp_rollout_expand_kernel<double>), ge, dim3(256), 0, st, (const double*)x, (const double*)ref, plan, tick, h->cfg.delta,
@@ -664,6 +671,10 @@ int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* x, void
                          (const float*)u, status, h->cfg.delta, (int)N, B, (int)T, it, (float*)actual, (float*)desired, (float*)forces, solved);
     const hipError_t he = hipGetLastError();
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "roll-out kernel launch", he);
+  }
+  if (timing) {
+    if (hipEventRecord(h->ev1, st) != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord");
+    h->timed = true;
   }
   return MPCQP_OK;
 }
@@ -689,6 +700,7 @@ int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* u, const void* jac, 
 
 int mpcqp_last_kernel_ms(mpcqp_handle h, float* ms) {
   if (!h || !ms) return MPCQP_EINVAL;
+  if (h->cfg.flags & MPCQP_FLAG_NO_TIMING) return fail(h, MPCQP_EINVAL, "mpcqp_last_kernel_ms: the handle was created with MPCQP_FLAG_NO_TIMING");
   if (!h->timed) return fail(h, MPCQP_EINVAL, "mpcqp_last_kernel_ms: no solve recorded");
   DeviceGuard guard(h->cfg.device);
   hipError_t he = hipEventSynchronize(h->ev1);

@@ -204,6 +204,19 @@ def test_edge_cases(oracle_solve):
     assert o["u"].shape == (0, 10, 12)
 
 
+def test_no_timing_flag(oracle_solve):
+    """MPCQP_FLAG_NO_TIMING: same results, no event pair around the solve, mpcqp_last_kernel_ms refuses."""
+    b = mpcqp.synth.config3(64)
+    ref = gpu_solve(b, io="f32", precision="mixed")
+    sol = mpcqp.MPCBatch(io_dtype="f32", precision="mixed", flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)
+    dev = sol.upload(b)
+    out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], want_X=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(out["u"].cpu().numpy(), ref["u"]) and np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    with pytest.raises(mpcqp.MpcQpError):
+        sol.last_kernel_ms()
+
+
 def test_operand_validation():
     sol = mpcqp.MPCBatch()
     b = sol.upload(mpcqp.synth.config2(4))
