@@ -867,7 +867,8 @@ MPCQP_PHASE void ph_output(TIO* __restrict__ ug, TIO* __restrict__ Xg, int* __re
 // (d / h) / mu > 1 means saturated cones, a large active set and slow ADMM convergence (two-legged "amble" support at
 // mu = 0.3: 95 % of those QPs trigger the rho adaptation; diagonal "trot" support: 1 %).  Order only: results are per QP.
 constexpr int ORDER_BUCKETS = 16;
-struct OrderBuf { int* cnt; int* list; int cap; int* head; };   // cnt[ORDER_BUCKETS], list[ORDER_BUCKETS][cap], queue head
+struct OrderBuf { int* cnt; int* list; int cap; int* head; int* zero; };   // cnt[ORDER_BUCKETS], list[ORDER_BUCKETS][cap], queue head;
+                                                                           // zero: the OTHER call's 32 header ints, cleared by this call's pre-pass
 
 __device__ __forceinline__ float support_demand(int nst, const float (&fx)[4], const float (&fy)[4], const float (&fz)[4],
                                                 const bool (&st)[4]) {
@@ -904,6 +905,9 @@ __global__ void __launch_bounds__(1024)
 mpcqp_order_kernel(const FastIn<TIO> in, const int B, const OrderBuf ob) {
   __shared__ int lcnt[ORDER_BUCKETS], lbase[ORDER_BUCKETS];
   if (threadIdx.x < ORDER_BUCKETS) lcnt[threadIdx.x] = 0;
+  // Two sets of class counters + queue head alternate between calls: this pre-pass counts into one (cleared by the previous call's
+  // pre-pass, whose solve has finished with it: one stream per handle) and clears the other for the next call -- no memset launch.
+  if (blockIdx.x == 0 && threadIdx.x < 32 && ob.zero) ob.zero[threadIdx.x] = 0;
   __syncthreads();
   const int b = blockIdx.x * 64 + (threadIdx.x >> 4), k0 = threadIdx.x & 15;
   float score = 0.f, cnt = 0.f;

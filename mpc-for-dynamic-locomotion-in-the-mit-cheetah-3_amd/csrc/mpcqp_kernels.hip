@@ -166,7 +166,8 @@ struct mpcqp_engine {
   double* ctab = nullptr;   // [2][N][N] coefficient tables on the device
   DevCfg* dcfg = nullptr;   // device copy of `dev`
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int* order_mem = nullptr;   // dispatch order of the fast path: [32 header ints: class counters, queue head | ORDER_BUCKETS x order_cap indices]
+  int* order_mem = nullptr;   // dispatch order: [2 x 32 header ints (class counters, queue head), alternating between calls | ORDER_BUCKETS x order_cap indices]
+  int order_phase = 0;        // which header set the next ordered launch counts into
   int order_cap = 0;
   int slots = 0;              // workgroups the device holds at once (2 per CU)
   double* wr_K = nullptr;     // wrench-space engine (mpcqp_wrench.h): K_q [6][N][N], K^-1 in tile layout (fp32 / fp64)
@@ -208,17 +209,26 @@ hipError_t launch(const mpcqp_engine* e, int64_t B, const void* x0, const void* 
 #ifndef MPCQP_DEBUG_DYN_LDS
 #define MPCQP_DEBUG_DYN_LDS 0   // occupancy experiments only: extra dynamic LDS per workgroup
 #endif
+// The order buffer of one ordered launch: header set `order_phase` (zeroed by the previous ordered launch's pre-pass, or at
+// allocation), the other set handed to this launch's pre-pass for clearing.
+static OrderBuf next_order_buf(mpcqp_engine* e) {
+  OrderBuf ob;
+  int* hdr = e->order_mem + 32 * e->order_phase;
+  ob.cnt = hdr; ob.head = hdr + ORDER_BUCKETS; ob.zero = e->order_mem + 32 * (1 - e->order_phase);
+  ob.list = e->order_mem + 64; ob.cap = e->order_cap;
+  e->order_phase ^= 1;
+  return ob;
+}
+
 // Fast path (mpcqp_fast.h): one launch, one QP per workgroup, phases as separately register-allocated device functions.
 template <typename TIO>
 hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
                        float* res, hipStream_t s) {
   dim3 grid((unsigned)B);
-  OrderBuf ob = {nullptr, nullptr, 0, nullptr};
+  OrderBuf ob = {nullptr, nullptr, 0, nullptr, nullptr};
   // dispatch order (mpcqp_fast.h): worth a pre-pass as soon as the batch oversubscribes the workgroup slots
   if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && e->slots > 0 && B > (int64_t)e->slots && e->order_cap >= B) {
-    ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 32; ob.cap = e->order_cap;
-    hipError_t he = hipMemsetAsync(ob.cnt, 0, 32 * sizeof(int), s);
-    if (he != hipSuccess) return he;
+    ob = next_order_buf(e);
     hipLaunchKernelGGL((mpcqp_order_kernel<TIO>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
     grid = dim3((unsigned)(B < e->slots ? B : e->slots));   // queued form: resident workgroups pull QPs
   }
@@ -237,13 +247,11 @@ template <typename TIO, int N>
 hipError_t launch_wrench(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
                          float* res, hipStream_t s) {
   dim3 grid((unsigned)B);
-  OrderBuf ob = {nullptr, nullptr, 0, nullptr};
+  OrderBuf ob = {nullptr, nullptr, 0, nullptr, nullptr};
   {
     const int64_t slots = (N == 10 ? 4 : 1) * (int64_t)e->slots;   // e->slots = 2 per CU: resident workgroups of the horizon-20 kernel
     if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && slots > 0 && B > slots && e->order_cap >= B) {
-      ob.cnt = e->order_mem; ob.head = e->order_mem + ORDER_BUCKETS; ob.list = e->order_mem + 32; ob.cap = e->order_cap;
-      hipError_t he = hipMemsetAsync(ob.cnt, 0, 32 * sizeof(int), s);
-      if (he != hipSuccess) return he;
+      ob = next_order_buf(e);
       hipLaunchKernelGGL((mpcqp_order_kernel<TIO, N>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
       // Up to a few device-fills the hardware's own dispatcher does better with the ordered list than resident workgroups on an
       // atomic queue (B = 4096: 0.53-0.56 ms against 0.60-0.63, tools/order_study.py): a resident wave stays on the SIMD it
@@ -278,9 +286,11 @@ int reserve_workspace(mpcqp_engine* e, int64_t B) {
   if (e->order_cap < B) {
     int* mem = nullptr;
     const int64_t cap = ((B + 1023) / 1024) * 1024;
-    if (hipMalloc(&mem, (size_t)(32 + ORDER_BUCKETS * cap) * sizeof(int)) == hipSuccess) {
-      if (e->order_mem) { (void)hipDeviceSynchronize(); (void)hipFree(e->order_mem); }   // queued work may still read the old one
-      e->order_mem = mem; e->order_cap = (int)cap;
+    if (hipMalloc(&mem, (size_t)(64 + ORDER_BUCKETS * cap) * sizeof(int)) == hipSuccess) {
+      (void)hipDeviceSynchronize();                                                      // queued work may still read the old one
+      if (e->order_mem) (void)hipFree(e->order_mem);
+      (void)hipMemset(mem, 0, 64 * sizeof(int));                                         // both header sets start cleared
+      e->order_mem = mem; e->order_cap = (int)cap; e->order_phase = 0;
     } else {
       (void)hipGetLastError();   // tolerated: the batch runs in natural order; do not leave the error for the launch check
     }
