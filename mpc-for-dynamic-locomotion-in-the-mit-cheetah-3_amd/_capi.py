@@ -227,5 +227,11 @@ def product_library() -> Library:
     """The HIP engine.  Raises (loudly) when the extension has not been built -- never falls back."""
     global _product
     if _product is None:
+        # PyTorch-ROCm carries its own HIP runtime: it has to be in the process BEFORE libmpcqp.so pulls in /opt/rocm's, or the
+        # one loaded second sees no device (mpcqp_create: MPCQP_ENODEV after `build()` + `smoke()` in one process, measured).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _product = Library(PRODUCT_LIB)
     return _product
