@@ -941,150 +941,275 @@ __device__ __forceinline__ void w_polish_sys(const SmemW<TV, N>& s, int L, const
   Ls.dinv[2] = a.ez ? (TP)((TV)1 / (a2 * ((TV)1 + muv * muv * (TV)((a.xs != 0) + (a.ys != 0))))) : (TP)0;
 }
 
-// One primal-dual active-set step from (s.pu, s.py) (OSQP's `polish`, specialised to the 5 rows of a leg-stage): fz at a
-// bound and/or fx, fy tied to +-mu fz per leg; the equality-constrained QP is solved in the free variables through the
-// wrench-space system in TP precision; duals from stationarity; accepted only on a KKT check.  Returns 1 when accepted
-// (answer in s.uv), else 0 with (s.pu, s.py) replaced by the candidate.
-// Three register phases (rule + E | tile + sweep | solve + KKT) that share nothing but LDS: the fp64 tile is half of the
-// register file, so whatever else stays alive across the sweep is spilled to scratch inside the pivot loop.  Each phase
-// re-derives its lane roles from an opaque copy of the lane index and re-reads its data from LDS.
+// The active-set rule of the polish on (s.pu, s.py) for one leg-stage: rows 0 fz | 1 fx - mu fz <= 0 | 2 fx + mu fz >= 0 | 3,4 the
+// same for fy -> ActSet code.
+template <typename TV, int N>
+__device__ __forceinline__ int w_polish_rule(const SmemW<TV, N>& s, const int L, const bool stance) {
+  const TV muv = s.mu, fminv = s.fmin, fmaxv = s.fmax;
+  int zs = 0, xs = 0, ys = 0;
+  if (stance) {
+    const TV u0 = s.pu[3 * L], u1 = s.pu[3 * L + 1], u2 = s.pu[3 * L + 2];
+    const TV y0 = s.py[5 * L], y1 = s.py[5 * L + 1], y2 = s.py[5 * L + 2], y3 = s.py[5 * L + 3], y4 = s.py[5 * L + 4];
+    const TV g1 = u0 - muv * u2, g2 = u0 + muv * u2, g3_ = u1 - muv * u2, g4 = u1 + muv * u2;
+    if (y0 + (u2 - fmaxv) > 0) zs = 1;
+    else if (y0 + (u2 - fminv) < 0) zs = -1;
+    const bool hx = y1 + g1 > 0, lx = y2 + g2 < 0;
+    if (hx && lx) xs = (g1 > -g2) ? 1 : -1; else if (hx) xs = 1; else if (lx) xs = -1;
+    const bool hy = y3 + g3_ > 0, ly = y4 + g4 < 0;
+    if (hy && ly) ys = (g3_ > -g4) ? 1 : -1; else if (hy) ys = 1; else if (ly) ys = -1;
+  }
+  return (zs + 1) | ((xs + 1) << 2) | ((ys + 1) << 4);
+}
+
+#ifndef MPCQP_W_INCR_LEGS
+#define MPCQP_W_INCR_LEGS 4     // leg-stages whose active set may change for the inverse to be updated instead of rebuilt
+#endif
+#ifndef MPCQP_W_INCR_STEPS
+#define MPCQP_W_INCR_STEPS 4    // updates in a row before a rebuild
+#endif
+
+// The polish steps of one round: primal-dual active-set steps from (s.pu, s.py) (OSQP's `polish`, specialised to the 5 rows of a
+// leg-stage): fz at a bound and/or fx, fy tied to +-mu fz per leg; the equality-constrained QP is solved in the free variables
+// through the wrench-space system in TP precision; duals from stationarity; a candidate is accepted only on a KKT check.
+// Returns 1 when a step was accepted (answer in s.uv), else 0 with (s.pu, s.py) the last candidate.  Up to `budget` steps, while
+// they make progress (patience rule below) unless `last`.
+// Register phases that share nothing but LDS and the tile: rule | E | tile + sweep | solve + KKT.  The fp64 tile is half of the
+// register file: it is defined at the top of the outer loop (a full build for the active set in s.aset) and only modified in the
+// inner loop, where a step that FOLLOWS another updates -S^-1 instead of rebuilding it: between consecutive steps the active set
+// changes on 1.8 leg-stages on average (<= 2 in 82 % of the steps, <= 5 in 97 %), and a changed leg-stage changes S = K^-1 + E by
+// at most three rank-one terms removed and three added -- Sherman-Morrison, one mat-vec and one rank-one tile update per term
+// (about two pivots' work) against the 60 pivots of a rebuild.  One wave per QP only; at most MPCQP_W_INCR_LEGS changed leg-stages
+// and MPCQP_W_INCR_STEPS updates in a row; a candidate from a drifted inverse would simply fail the KKT test.
 template <typename TV, typename TP, int N>
-__device__ __forceinline__ int w_polish(SmemW<TV, N>& s, const WrTabs& tabs, const TP* __restrict__ kinvT, const int tid0) {
+__device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tabs, const TP* __restrict__ kinvT, const int tid0,
+                                              const int budget, const bool last, const int trace_tag) {
   constexpr int NL = WG<N>::NL, NW = WG<N>::NW, G = WG<N>::G;
+  constexpr int STG = 2 * 21 + 1;   // staging record of a changed leg-stage in s.E: removed | added {A[3][6], weight[3]}, stage index
   TP* const E = reinterpret_cast<TP*>(s.E);
   TP* const piv = reinterpret_cast<TP*>(s.piv);
   TP* const bv = reinterpret_cast<TP*>(s.bv);
   TP* const cv = reinterpret_cast<TP*>(s.cv);
   STAMP_INIT
-  {   // ---- phase A: active-set rule on (pu, py): rows 0 fz | 1 fx - mu fz <= 0 | 2 fx + mu fz >= 0 | 3,4 same for fy
+  {   // ---- the first step's active set
     const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1);
-    const bool stance = s.ct[L] != 0;
-    const TV muv = s.mu, fminv = s.fmin, fmaxv = s.fmax;
-    int zs = 0, xs = 0, ys = 0;
-    if (stance) {
-      const TV u0 = s.pu[3 * L], u1 = s.pu[3 * L + 1], u2 = s.pu[3 * L + 2];
-      const TV y0 = s.py[5 * L], y1 = s.py[5 * L + 1], y2 = s.py[5 * L + 2], y3 = s.py[5 * L + 3], y4 = s.py[5 * L + 4];
-      const TV g1 = u0 - muv * u2, g2 = u0 + muv * u2, g3_ = u1 - muv * u2, g4 = u1 + muv * u2;
-      if (y0 + (u2 - fmaxv) > 0) zs = 1;
-      else if (y0 + (u2 - fminv) < 0) zs = -1;
-      const bool hx = y1 + g1 > 0, lx = y2 + g2 < 0;
-      if (hx && lx) xs = (g1 > -g2) ? 1 : -1; else if (hx) xs = 1; else if (lx) xs = -1;
-      const bool hy = y3 + g3_ > 0, ly = y4 + g4 < 0;
-      if (hy && ly) ys = (g3_ > -g4) ? 1 : -1; else if (hy) ys = 1; else if (ly) ys = -1;
-    }
-    const int code = (zs + 1) | ((xs + 1) << 2) | ((ys + 1) << 4);
+    const int code = w_polish_rule<TV, N>(s, L, s.ct[L] != 0);
     if (tid < NL) s.aset[L] = (uint8_t)code;
-    const ActSet as(code, stance);
-    LegSys<TP> Ls;
-    w_polish_sys<TV, TP, N>(s, L, as, Ls);
-    wsync<NW>();   // everyone has read pu / py of this round
-    w_build_E<TP, N>(Ls, E, tid);
-  }
-  STAMP(9);
-  WTile<TP> tile;
-  {   // ---- phase B: S = K^-1 + E, swept in place
-    const int tid = fresh_tid<NW>(tid0), gr = tid / G, gc = tid % G;
-    w_tile_init<TP, N>(tile, kinvT, E, gr, gc, tid);
-    STAMP(10);
-    w_sweep<TP, N>(tile, piv, gr, gc);
-  }
-  STAMP(11);
-  // ---- phase C: solve in the free variables from the projection of pu, duals, KKT
-  const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1), gr = tid / G, gc = tid % G;
-  const bool leg = tid < NL, stance = s.ct[L] != 0;
-  if (tid >= WG<N>::NQ && tid < WG<N>::DP) bv[tid] = (TP)0;   // pad slots of the mat-vec input, in this phase's element type
-  const ActSet as(s.aset[L], stance);
-  const int zs = as.zs, xs = as.xs, ys = as.ys;
-  const bool ez = as.ez, ex = as.ex, ey = as.ey;
-  // (only what the refinement loop needs is read here: the loop carries the fp64 tile, and every extra live value is a spill)
-  TV txs, tys;
-  TV v3[3];   // the reduced variables; where a component is fixed (bound / tied / swing) v3 holds its fixed value instead
-  {
-    const TV muv = s.mu;
-    txs = (TV)xs * muv; tys = (TV)ys * muv;
-    const TV F = zs > 0 ? (TV)s.fmax : (TV)s.fmin;
-    v3[0] = ex ? s.pu[3 * L] : (TV)0; v3[1] = ey ? s.pu[3 * L + 1] : (TV)0;
-    v3[2] = ez ? s.pu[3 * L + 2] : ((stance && zs != 0) ? F : (TV)0);
-  }
-  TV uc[3], gr3[3] = {0, 0, 0};
-  auto expand = [&]() {
-    uc[2] = v3[2];
-    uc[0] = ex ? v3[0] : txs * v3[2];
-    uc[1] = ey ? v3[1] : tys * v3[2];
-  };
-  float stat = INFINITY, prev = INFINITY;
-  for (int rf = 0;; ++rf) {
-    expand();
-    if (leg) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) s.uv[3 * L + c] = uc[c];
-    }
     wsync<NW>();
-    w_grad<TV, N>(s, tabs.K, tid, gr3);
-    TV rg[3] = {ex ? gr3[0] : (TV)0, ey ? gr3[1] : (TV)0, ez ? gr3[2] + txs * gr3[0] + tys * gr3[1] : (TV)0};
-    float q[2] = {leg ? fmaxf(fmaxf(fabsf((float)rg[0]), fabsf((float)rg[1])), fabsf((float)rg[2])) : 0.f,
-                  leg ? fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2])) : 0.f};
-    if (!isfinite(q[0])) q[0] = INFINITY;
-    wmax<2, NW>(q, s.red, tid);
-    prev = stat; stat = ufloat(q[0]);
-    // refine until the stationarity residual is safely below what the acceptance test will ask for (it scales with 2 alpha:
-    // binding for alpha < 1e-2, where one fp64 solve -- residual ~1e-9 |g| -- is not enough)
-    const float gmaxl = s.gmax;
-    const float tol_stat = (sizeof(TV) == 8) ? (1e-6f + 1e-9f * gmaxl) : (3e-7f * fmaxf(gmaxl, 1.f));
-    const float tol = fminf(tol_stat, 0.25f * ((sizeof(TV) == 8) ? 2.f * (float)s.alpha : 1e30f) * 2e-5f * fmaxf(1.f, q[1]));
-    if (stat <= tol || rf >= 4 || (rf > 0 && !(stat < 0.5f * prev))) break;   // converged / stagnated (uniform)
-    const TP rhs[3] = {(TP)(-rg[0]), (TP)(-rg[1]), (TP)(-rg[2])};
-    TP dx[3];
-    {
+  }
+  int ok = 0, ps = 0;
+  float vprev = INFINITY, vprev2 = INFINITY;
+  bool done = false;
+  while (!done) {
+    {   // ---- E = T D^-1 T' for the active set in s.aset
+      const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1);
       LegSys<TP> Ls;
-      w_polish_sys<TV, TP, N>(s, L, as, Ls);
-      w_solve<TP, N>(tile, Ls, rhs, dx, bv, cv, tid, gr, gc);
+      w_polish_sys<TV, TP, N>(s, L, ActSet(s.aset[L], s.ct[L] != 0), Ls);
+      w_build_E<TP, N>(Ls, E, tid);
     }
-    v3[0] += ex ? (TV)dx[0] : (TV)0; v3[1] += ey ? (TV)dx[1] : (TV)0; v3[2] += ez ? (TV)dx[2] : (TV)0;
-  }
-  // duals from stationarity grad_leg + G_A' y_A = 0, then primal feasibility + dual sign
-  const TV muv = s.mu, fminv = s.fmin, fmaxv = s.fmax;
-  const float gmaxf = s.gmax;
-  const float acc_stat = (sizeof(TV) == 8) ? (1e-5f + 1e-8f * gmaxf) : (1e-5f * fmaxf(gmaxf, 1.f));
-  const float ftol = (sizeof(TV) == 8) ? 1e-7f : 2e-5f;
-  const float dtol = (sizeof(TV) == 8) ? (1e-5f + 1e-9f * gmaxf) : (2e-5f * fmaxf(1.f, gmaxf));
-  TV yn[5] = {0, 0, 0, 0, 0};
-  float viol[3] = {0.f, 0.f, 0.f};
-  if (leg && stance) {
-    TV zacc = gr3[2];
-    if (xs > 0) { yn[1] = -gr3[0]; zacc += muv * (-yn[1]); }
-    else if (xs < 0) { yn[2] = -gr3[0]; zacc += muv * yn[2]; }
-    if (ys > 0) { yn[3] = -gr3[1]; zacc += muv * (-yn[3]); }
-    else if (ys < 0) { yn[4] = -gr3[1]; zacc += muv * yn[4]; }
-    if (zs != 0) yn[0] = -zacc;
-    const TV g0 = uc[2], g1 = uc[0] - muv * uc[2], g2 = uc[0] + muv * uc[2], g3_ = uc[1] - muv * uc[2], g4 = uc[1] + muv * uc[2];
-    TV pv = fmax(fminv - g0, g0 - fmaxv);
-    pv = fmax(pv, fmax(g1, -g2));
-    pv = fmax(pv, fmax(g3_, -g4));
-    TV dv = fmax(fmax(-yn[1], yn[2]), fmax(-yn[3], yn[4]));
-    if (zs > 0) dv = fmax(dv, -yn[0]);
-    if (zs < 0) dv = fmax(dv, yn[0]);
-    viol[0] = (float)fmax(pv, (TV)0);
-    viol[1] = (float)fmax(dv, (TV)0);
-    viol[2] = fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2]));
-    if (!(isfinite(viol[0]) && isfinite(viol[1]))) viol[0] = viol[1] = INFINITY;
-  }
-  wmax<3, NW>(viol, s.red, tid);
-  // a stationarity / dual-sign slack e moves the forces by ~e / (2 alpha): scale the acceptance with the curvature so that
-  // `solved` implies the 1e-4 band for any alpha
-  const float a2f = (sizeof(TV) == 8) ? 2.f * (float)s.alpha : 1e30f, uscale = fmaxf(1.f, viol[2]);
-  const bool ok = viol[0] <= ftol * uscale && viol[1] <= fminf(dtol, a2f * 1e-5f * uscale) && stat <= fminf(acc_stat, a2f * 2e-5f * uscale);
-  STAMP(6);
-  if (leg) {   // publish the candidate as the next polish iterate / the answer (s.uv already holds it)
+    STAMP(9);
+    WTile<TP> tile;
+    {   // ---- S = K^-1 + E, swept in place
+      const int tid = fresh_tid<NW>(tid0), gr = tid / G, gc = tid % G;
+      w_tile_init<TP, N>(tile, kinvT, E, gr, gc, tid);
+      STAMP(10);
+      w_sweep<TP, N>(tile, piv, gr, gc);
+    }
+    STAMP(11);
+    int in_row = 0;
+    for (;;) {
+      int step_ok_i;
+      {
+      // ---- phase C: solve in the free variables from the projection of pu, duals, KKT
+      const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1), gr = tid / G, gc = tid % G;
+      const bool leg = tid < NL, stance = s.ct[L] != 0;
+      if (tid >= WG<N>::NQ && tid < WG<N>::DP) bv[tid] = (TP)0;   // pad slots of the mat-vec input, in this phase's element type
+      const ActSet as(s.aset[L], stance);
+      const int zs = as.zs, xs = as.xs, ys = as.ys;
+      const bool ez = as.ez, ex = as.ex, ey = as.ey;
+      // (only what the refinement loop needs is read here: the loop carries the fp64 tile, and every extra live value is a spill)
+      TV txs, tys;
+      TV v3[3];   // the reduced variables; where a component is fixed (bound / tied / swing) v3 holds its fixed value instead
+      {
+        const TV muv = s.mu;
+        txs = (TV)xs * muv; tys = (TV)ys * muv;
+        const TV F = zs > 0 ? (TV)s.fmax : (TV)s.fmin;
+        v3[0] = ex ? s.pu[3 * L] : (TV)0; v3[1] = ey ? s.pu[3 * L + 1] : (TV)0;
+        v3[2] = ez ? s.pu[3 * L + 2] : ((stance && zs != 0) ? F : (TV)0);
+      }
+      TV uc[3], gr3[3] = {0, 0, 0};
+      auto expand = [&]() {
+        uc[2] = v3[2];
+        uc[0] = ex ? v3[0] : txs * v3[2];
+        uc[1] = ey ? v3[1] : tys * v3[2];
+      };
+      float stat = INFINITY, prev = INFINITY;
+      for (int rf = 0;; ++rf) {
+        expand();
+        if (leg) {
+    #pragma unroll
+          for (int c = 0; c < 3; ++c) s.uv[3 * L + c] = uc[c];
+        }
+        wsync<NW>();
+        w_grad<TV, N>(s, tabs.K, tid, gr3);
+        TV rg[3] = {ex ? gr3[0] : (TV)0, ey ? gr3[1] : (TV)0, ez ? gr3[2] + txs * gr3[0] + tys * gr3[1] : (TV)0};
+        float q[2] = {leg ? fmaxf(fmaxf(fabsf((float)rg[0]), fabsf((float)rg[1])), fabsf((float)rg[2])) : 0.f,
+                      leg ? fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2])) : 0.f};
+        if (!isfinite(q[0])) q[0] = INFINITY;
+        wmax<2, NW>(q, s.red, tid);
+        prev = stat; stat = ufloat(q[0]);
+        // refine until the stationarity residual is safely below what the acceptance test will ask for (it scales with 2 alpha:
+        // binding for alpha < 1e-2, where one fp64 solve -- residual ~1e-9 |g| -- is not enough)
+        const float gmaxl = s.gmax;
+        const float tol_stat = (sizeof(TV) == 8) ? (1e-6f + 1e-9f * gmaxl) : (3e-7f * fmaxf(gmaxl, 1.f));
+        const float tol = fminf(tol_stat, 0.25f * ((sizeof(TV) == 8) ? 2.f * (float)s.alpha : 1e30f) * 2e-5f * fmaxf(1.f, q[1]));
+        if (stat <= tol || rf >= 4 || (rf > 0 && !(stat < 0.5f * prev))) break;   // converged / stagnated (uniform)
+        const TP rhs[3] = {(TP)(-rg[0]), (TP)(-rg[1]), (TP)(-rg[2])};
+        TP dx[3];
+        {
+          LegSys<TP> Ls;
+          w_polish_sys<TV, TP, N>(s, L, as, Ls);
+          w_solve<TP, N>(tile, Ls, rhs, dx, bv, cv, tid, gr, gc);
+        }
+        v3[0] += ex ? (TV)dx[0] : (TV)0; v3[1] += ey ? (TV)dx[1] : (TV)0; v3[2] += ez ? (TV)dx[2] : (TV)0;
+      }
+      // duals from stationarity grad_leg + G_A' y_A = 0, then primal feasibility + dual sign
+      const TV muv = s.mu, fminv = s.fmin, fmaxv = s.fmax;
+      const float gmaxf = s.gmax;
+      const float acc_stat = (sizeof(TV) == 8) ? (1e-5f + 1e-8f * gmaxf) : (1e-5f * fmaxf(gmaxf, 1.f));
+      const float ftol = (sizeof(TV) == 8) ? 1e-7f : 2e-5f;
+      const float dtol = (sizeof(TV) == 8) ? (1e-5f + 1e-9f * gmaxf) : (2e-5f * fmaxf(1.f, gmaxf));
+      TV yn[5] = {0, 0, 0, 0, 0};
+      float viol[3] = {0.f, 0.f, 0.f};
+      if (leg && stance) {
+        TV zacc = gr3[2];
+        if (xs > 0) { yn[1] = -gr3[0]; zacc += muv * (-yn[1]); }
+        else if (xs < 0) { yn[2] = -gr3[0]; zacc += muv * yn[2]; }
+        if (ys > 0) { yn[3] = -gr3[1]; zacc += muv * (-yn[3]); }
+        else if (ys < 0) { yn[4] = -gr3[1]; zacc += muv * yn[4]; }
+        if (zs != 0) yn[0] = -zacc;
+        const TV g0 = uc[2], g1 = uc[0] - muv * uc[2], g2 = uc[0] + muv * uc[2], g3_ = uc[1] - muv * uc[2], g4 = uc[1] + muv * uc[2];
+        TV pv = fmax(fminv - g0, g0 - fmaxv);
+        pv = fmax(pv, fmax(g1, -g2));
+        pv = fmax(pv, fmax(g3_, -g4));
+        TV dv = fmax(fmax(-yn[1], yn[2]), fmax(-yn[3], yn[4]));
+        if (zs > 0) dv = fmax(dv, -yn[0]);
+        if (zs < 0) dv = fmax(dv, yn[0]);
+        viol[0] = (float)fmax(pv, (TV)0);
+        viol[1] = (float)fmax(dv, (TV)0);
+        viol[2] = fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2]));
+        if (!(isfinite(viol[0]) && isfinite(viol[1]))) viol[0] = viol[1] = INFINITY;
+      }
+      wmax<3, NW>(viol, s.red, tid);
+      // a stationarity / dual-sign slack e moves the forces by ~e / (2 alpha): scale the acceptance with the curvature so that
+      // `solved` implies the 1e-4 band for any alpha
+      const float a2f = (sizeof(TV) == 8) ? 2.f * (float)s.alpha : 1e30f, uscale = fmaxf(1.f, viol[2]);
+      const bool step_ok = viol[0] <= ftol * uscale && viol[1] <= fminf(dtol, a2f * 1e-5f * uscale) && stat <= fminf(acc_stat, a2f * 2e-5f * uscale);
+      STAMP(6);
+      if (leg) {   // publish the candidate as the next polish iterate / the answer (s.uv already holds it)
+    #pragma unroll
+        for (int c = 0; c < 3; ++c) s.pu[3 * L + c] = uc[c];
+    #pragma unroll
+        for (int i = 0; i < 5; ++i) s.py[5 * L + i] = yn[i];
+      }
+      if (tid == 0) { s.kkt[0] = stat; s.kkt[1] = viol[0]; s.kkt[2] = viol[1]; s.psteps += 1; }
+      wsync<NW>();
+        step_ok_i = step_ok ? 1 : 0;
+      }
+      STAMP(7);
+      ok = __builtin_amdgcn_readfirstlane(step_ok_i);
+      const float v = ufloat(s.kkt[1] + s.kkt[2] / fmaxf(s.gmax, 1.f) * 100.f);
+#if defined(MPCQP_STAMPS)   // (diagnostic build, single-QP launches: a trace of the polish steps, tools/hardest.py)
+      if (trace_tag >= 0 && fresh_tid<NW>(tid0) == 0 && s.psteps <= 80) {
+        double* rec = g_wdbg + 1300 + 8 * (s.psteps - 1);
+        rec[0] = trace_tag; rec[1] = ps; rec[2] = s.kkt[0]; rec[3] = s.kkt[1]; rec[4] = s.kkt[2]; rec[5] = s.rho; rec[6] = s.iters; rec[7] = ok + 10 * in_row;
+      }
+#endif
+      ++ps;
+      if (ok || ps >= budget) { done = true; break; }
+      {
+        // Active-set steps while they make progress: a step that does not at least halve the KKT violation of the previous one
+        // (primal + dual-sign, each relative to its scale) means ADMM has not settled the active set yet -- back to ADMM rather
+        // than through the rest of the budget (each rebuilt step costs an fp64 sweep, about 50 ADMM iterations) -- except that the
+        // candidates of a converging sequence often ALTERNATE between a primal-feasible one with a wrong multiplier sign and a
+        // dual-feasible one with a small constraint violation (the hardest QP of the bench batch lost two ADMM rounds to being cut
+        // one step short, tools/hardest.py): such a one-sided candidate is compared with the one two steps before it, like with
+        // like, for up to two extra steps.
+        const int psd = ps - 1;
+        const bool one_sided = fminf(s.kkt[1], s.kkt[2]) <= 1e-9f;
+        const bool stalled = !(v < 0.5f * vprev);
+        const bool alternating = one_sided && psd >= 2 && psd < 4 && v < 0.5f * vprev2;
+        if (psd >= POLISH_PATIENCE && stalled && !alternating && !last) { done = true; break; }   // uniform
+      }
+      vprev2 = vprev; vprev = v;
+      // ---- the next step's active set; what changed is staged for an update of the inverse
+      int nupd = 0;
+      bool incr = false;
+      {
+        const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1);
+        const bool stance = s.ct[L] != 0;
+        const int code = w_polish_rule<TV, N>(s, L, stance);
+        if constexpr (NW == 1) {
+          const bool chg = tid < NL && stance && s.aset[L] != (uint8_t)code;
+          const unsigned long long mask = __ballot(chg);
+          nupd = __builtin_popcountll(mask);
+          incr = in_row < MPCQP_W_INCR_STEPS && nupd <= MPCQP_W_INCR_LEGS;
+          if (incr && chg) {
+            TP* rec = E + STG * __builtin_popcountll(mask & ((1ull << tid) - 1ull));
+            LegSys<TP> Lo;
+            w_polish_sys<TV, TP, N>(s, L, ActSet(s.aset[L], stance), Lo);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) s.pu[3 * L + c] = uc[c];
+            for (int c = 0; c < 3; ++c) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) s.py[5 * L + i] = yn[i];
+              for (int q = 0; q < 6; ++q) rec[6 * c + q] = Lo.A[c][q];
+              rec[18 + c] = -Lo.dinv[c];
+            }
+            w_polish_sys<TV, TP, N>(s, L, ActSet(code, stance), Lo);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+              for (int q = 0; q < 6; ++q) rec[21 + 6 * c + q] = Lo.A[c][q];
+              rec[21 + 18 + c] = Lo.dinv[c];
+            }
+            rec[42] = (TP)(L >> 2);
+          }
+        }
+        if (tid < NL) s.aset[L] = (uint8_t)code;
+        wsync<NW>();
+      }
+      if (!incr) break;   // rebuild for the new active set (outer loop)
+      {   // ---- -S^-1 updated term by term:  S' = S + w a a'  =>  -S'^-1 = -S^-1 + w / (1 + w a'y) y y',  y = S^-1 a
+        const int tid = fresh_tid<NW>(tid0), gr = tid / G, gc = tid % G;
+        for (int k = 0; k < nupd; ++k) {
+          const TP* rec = E + STG * k;
+          const int j = (int)rec[42];
+          for (int h = 0; h < 6; ++h) {
+            const TP* a = rec + 21 * (h / 3) + 6 * (h % 3);
+            const TP wgt = rec[21 * (h / 3) + 18 + h % 3];
+            if (wgt == (TP)0) continue;          // uniform
+            if (tid < WG<N>::DP) bv[tid] = (tid >= 6 * j && tid < 6 * j + 6) ? a[tid - 6 * j] : (TP)0;
+            wsync<NW>();
+            w_matvec<TP, N>(tile, bv, cv, gr, gc);
+            wsync<NW>();
+            TP gam = (TP)0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) gam = fma(a[q], cv[6 * j + q], gam);
+            const TP beta = wgt / ((TP)1 + wgt * gam);
+            TP yr[8], yc[8];
+            ld8<TP>(cv + 8 * gr, yr);
+            ld8<TP>(cv + 8 * gc, yc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) yr[i] *= -beta;
+            rank1(tile, yr, yc);
+            tpin(tile);
+            wsync<NW>();
+          }
+        }
+        ++in_row;
+      }
+      STAMP(12);
+    }
   }
-  if (tid == 0) { s.kkt[0] = stat; s.kkt[1] = viol[0]; s.kkt[2] = viol[1]; s.psteps += 1; }
-  wsync<NW>();
-  STAMP(7);
-  return ok ? 1 : 0;
+  return ok;
 }
 
 // ----------------------------------------------------------------------------------------------------- output
@@ -1251,28 +1376,12 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       // (primal + dual-sign, each relative to its scale) means ADMM has not settled the active set yet -- back to ADMM rather
       // than through the rest of the budget (each step costs an fp64 sweep, about 50 ADMM iterations).
       const bool last = kind != R_ADMM || __builtin_amdgcn_readfirstlane(s.iters) >= max_iter;   // (a round that nothing follows keeps its full budget)
-      float vprev = INFINITY, vprev2 = INFINITY;
-      for (int ps = 0; ps < budget && !ok; ++ps) {
-        ok = __builtin_amdgcn_readfirstlane(w_polish<TV, TP, N>(s, tabs, kinvP, tid0));
-        const float v = ufloat(s.kkt[1] + s.kkt[2] / fmaxf(s.gmax, 1.f) * 100.f);
-#if defined(MPCQP_STAMPS)   // (diagnostic build, single-QP launches: a trace of the polish steps, tools/hardest.py)
-        if (Btot == 1 && fresh_tid<NW>(tid0) == 0 && s.psteps <= 80) {
-          double* rec = g_wdbg + 1300 + 8 * (s.psteps - 1);
-          rec[0] = kind * 100 + round; rec[1] = ps; rec[2] = s.kkt[0]; rec[3] = s.kkt[1]; rec[4] = s.kkt[2]; rec[5] = s.rho; rec[6] = s.iters; rec[7] = ok;
-        }
+#ifdef MPCQP_STAMPS
+      const int trace_tag = Btot == 1 ? kind * 100 + round : -1;
+#else
+      const int trace_tag = -1;
 #endif
-        {
-          // ... except that the candidates of a converging sequence often ALTERNATE between a primal-feasible one with a wrong
-          // multiplier sign and a dual-feasible one with a small constraint violation (the hardest QP of the bench batch lost two
-          // ADMM rounds to being cut one step short, tools/hardest.py): such a one-sided candidate is compared with the one two
-          // steps before it, like with like, for up to two extra steps.
-          const bool one_sided = fminf(s.kkt[1], s.kkt[2]) <= 1e-9f;
-          const bool stalled = !(v < 0.5f * vprev);
-          const bool alternating = one_sided && ps >= 2 && ps < 4 && v < 0.5f * vprev2;
-          if (!ok && ps >= POLISH_PATIENCE && stalled && !alternating && !last) break;   // uniform
-        }
-        vprev2 = vprev; vprev = v;
-      }
+      if (budget > 0) ok = __builtin_amdgcn_readfirstlane(w_polish_round<TV, TP, N>(s, tabs, kinvP, tid0, budget, last, trace_tag));
       if (ok == 1 && s.alpha > s.alpha_target) {   // next continuation level, from this optimum and its multipliers
         const int tid = fresh_tid<NW>(tid0);
         for (int i = tid; i < n; i += NT) s.ua[i] = s.uv[i];            // the last accepted answer and its multipliers (the ADMM
