@@ -962,10 +962,11 @@ __device__ __forceinline__ int w_polish_rule(const SmemW<TV, N>& s, const int L,
 }
 
 #ifndef MPCQP_W_INCR_LEGS
-#define MPCQP_W_INCR_LEGS 4     // leg-stages whose active set may change for the inverse to be updated instead of rebuilt
+#define MPCQP_W_INCR_LEGS 8     // leg-stages whose active set may change for the inverse to be updated instead of rebuilt
 #endif
 #ifndef MPCQP_W_INCR_STEPS
-#define MPCQP_W_INCR_STEPS 4    // updates in a row before a rebuild
+#define MPCQP_W_INCR_STEPS 12   // updates in a row before a rebuild (caps chosen on batches of other seeds: 2/4, 4/4, 6/8, 8/12
+                                //  give 0.54 / 0.51 / 0.51 / 0.50 ms at B = 4096, identical step counts and solved sets)
 #endif
 
 // The polish steps of one round: primal-dual active-set steps from (s.pu, s.py) (OSQP's `polish`, specialised to the 5 rows of a
@@ -985,6 +986,7 @@ __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tab
                                               const int budget, const bool last, const int trace_tag) {
   constexpr int NL = WG<N>::NL, NW = WG<N>::NW, G = WG<N>::G;
   constexpr int STG = 2 * 21 + 1;   // staging record of a changed leg-stage in s.E: removed | added {A[3][6], weight[3]}, stage index
+  static_assert(NW > 1 || STG * MPCQP_W_INCR_LEGS <= N * 36, "the staging records share the bytes of E");
   TP* const E = reinterpret_cast<TP*>(s.E);
   TP* const piv = reinterpret_cast<TP*>(s.piv);
   TP* const bv = reinterpret_cast<TP*>(s.bv);
