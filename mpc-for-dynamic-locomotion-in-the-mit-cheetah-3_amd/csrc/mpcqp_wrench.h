@@ -73,6 +73,7 @@ struct SmemW {
   float resid[4];                // residuals of the last ADMM iterate that w_ratio looked at
   float gmax, rho, ratio;
   int iters, psteps, hard, warm, bad;
+  unsigned chgmask[(Geo::NL + 31) / 32];   // four waves per QP: leg-stages whose active set changed (polish)
   uint8_t ct[Geo::NL];
   uint8_t aset[Geo::NL];         // active set of the current polish step (ActSet code)
 };
@@ -979,14 +980,14 @@ __device__ __forceinline__ int w_polish_rule(const SmemW<TV, N>& s, const int L,
 // inner loop, where a step that FOLLOWS another updates -S^-1 instead of rebuilding it: between consecutive steps the active set
 // changes on 1.8 leg-stages on average (<= 2 in 82 % of the steps, <= 5 in 97 %), and a changed leg-stage changes S = K^-1 + E by
 // at most three rank-one terms removed and three added -- Sherman-Morrison, one mat-vec and one rank-one tile update per term
-// (about two pivots' work) against the 60 pivots of a rebuild.  One wave per QP only; at most MPCQP_W_INCR_LEGS changed leg-stages
+// (about two pivots' work) against the 6 N pivots of a rebuild.  At most MPCQP_W_INCR_LEGS changed leg-stages
 // and MPCQP_W_INCR_STEPS updates in a row; a candidate from a drifted inverse would simply fail the KKT test.
 template <typename TV, typename TP, int N>
 __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tabs, const TP* __restrict__ kinvT, const int tid0,
                                               const int budget, const bool last, const int trace_tag) {
   constexpr int NL = WG<N>::NL, NW = WG<N>::NW, G = WG<N>::G;
   constexpr int STG = 2 * 21 + 1;   // staging record of a changed leg-stage in s.E: removed | added {A[3][6], weight[3]}, stage index
-  static_assert(NW > 1 || STG * MPCQP_W_INCR_LEGS <= N * 36, "the staging records share the bytes of E");
+  static_assert(STG * MPCQP_W_INCR_LEGS <= N * 36, "the staging records share the bytes of E");
   TP* const E = reinterpret_cast<TP*>(s.E);
   TP* const piv = reinterpret_cast<TP*>(s.piv);
   TP* const bv = reinterpret_cast<TP*>(s.bv);
@@ -1150,13 +1151,29 @@ __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tab
         const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1);
         const bool stance = s.ct[L] != 0;
         const int code = w_polish_rule<TV, N>(s, L, stance);
-        if constexpr (NW == 1) {
+        {
           const bool chg = tid < NL && stance && s.aset[L] != (uint8_t)code;
-          const unsigned long long mask = __ballot(chg);
-          nupd = __builtin_popcountll(mask);
+          int slot = 0;
+          if constexpr (NW == 1) {
+            const unsigned long long mask = __ballot(chg);
+            nupd = __builtin_popcountll(mask);
+            slot = __builtin_popcountll(mask & ((1ull << tid) - 1ull));
+          } else {   // four waves: a bit mask in LDS; slots in leg order, so that the result does not depend on arrival order
+            constexpr int NM = (NL + 31) / 32;
+            if (tid < NM) s.chgmask[tid] = 0u;
+            wsync<NW>();
+            if (chg) atomicOr(&s.chgmask[L >> 5], 1u << (L & 31));
+            wsync<NW>();
+#pragma unroll
+            for (int w = 0; w < NM; ++w) {
+              const unsigned m = s.chgmask[w];
+              nupd += __builtin_popcount(m);
+              slot += w < (L >> 5) ? __builtin_popcount(m) : (w == (L >> 5) ? __builtin_popcount(m & ((1u << (L & 31)) - 1u)) : 0);
+            }
+          }
           incr = in_row < MPCQP_W_INCR_STEPS && nupd <= MPCQP_W_INCR_LEGS;
           if (incr && chg) {
-            TP* rec = E + STG * __builtin_popcountll(mask & ((1ull << tid) - 1ull));
+            TP* rec = E + STG * slot;
             LegSys<TP> Lo;
             w_polish_sys<TV, TP, N>(s, L, ActSet(s.aset[L], stance), Lo);
 #pragma unroll
