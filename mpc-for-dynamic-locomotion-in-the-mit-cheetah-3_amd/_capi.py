@@ -98,6 +98,10 @@ class Library:
             cfg.check_every = max(1, cfg.check_every * n // 10)
             if "max_iter" not in overrides:
                 cfg.max_iter = max(1, cfg.max_iter * n // 10)
+        # ... and so is the polish budget per round: twice the leg-stages, twice the steps (N = 20, eight batches of 4096: 14 -> 3
+        # QPs left at the iteration cap at the same rate, tools/adapt_sweep.py; the steps inside a round update the inverse)
+        if n != 10 and "polish_max" not in overrides:
+            cfg.polish_max = max(1, cfg.polish_max * n // 10)
         for k, v in overrides.items():
             if k in ("w", "Ibody_inv"):
                 arr = getattr(cfg, k)

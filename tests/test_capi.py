@@ -48,7 +48,8 @@ def test_host_layer_scales_the_admm_block_with_the_horizon(oracle_lib):
     other horizons unless the caller says otherwise (include/mpcqp.h, `check_every`)."""
     for lib in (oracle_lib, mpcqp.product_library()):
         c10, c20 = lib.default_config(), lib.default_config(N=20)
-        assert (c20.check_every, c20.max_iter) == (2 * c10.check_every, 2 * c10.max_iter)
+        assert (c20.check_every, c20.max_iter, c20.polish_max) == (2 * c10.check_every, 2 * c10.max_iter, 2 * c10.polish_max)
+        assert lib.default_config(N=20, polish_max=3).polish_max == 3
         c = lib.default_config(N=20, check_every=50)
         assert (c.check_every, c.max_iter) == (50, c10.max_iter)
         assert lib.default_config(N=20, max_iter=1000).max_iter == 1000

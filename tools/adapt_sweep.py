@@ -19,7 +19,8 @@ for name, batch in cases:
     B = len(batch["x0"])
     for thr in thrs:
         os.environ["MPCQP_ADAPT_THR"] = str(thr)
-        sol = mpcqp.MPCBatch(N=N, delta=0.03, precision=prec)
+        kw = {"polish_max": int(os.environ["SW_PM"])} if os.environ.get("SW_PM") else {}
+        sol = mpcqp.MPCBatch(N=N, delta=0.03, precision=prec, **kw)
         dev = sol.upload(batch)
         ms = []
         for _ in range(9):
