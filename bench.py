@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="QPs per GPU")
     ap.add_argument("--precision", default="mixed", choices=["f32", "mixed", "f64"])
     ap.add_argument("--allgather", action="store_true", help="all-gather stage-0 GRFs over RCCL every step")
+    ap.add_argument("--distinct-shards", action="store_true", help="N > 1: every rank draws its own batch (seed + rank) instead of the configured one")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the secondary per-gait / all-stance figures")
@@ -180,7 +181,10 @@ def main():
 
     N, delta, B = 10, 0.03, args.batch
     gaits, mus = ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0)
-    batch = mpcqp.synth.make_batch(B, N, delta, 20250809 + rank, gaits, mus)      # this rank's shard
+    # this rank's shard.  Weak scaling = the same work on every GPU: each rank solves the configured batch itself (same seed); with
+    # --distinct-shards each rank draws its own (seed + rank) -- then the job is as slow as the unluckiest draw (a launch of 4096 is
+    # as long as its longest QPs: +-15 % between seeds), which says nothing about the GPUs.
+    batch = mpcqp.synth.make_batch(B, N, delta, 20250809 + (rank if args.distinct_shards else 0), gaits, mus)
     # (MPCQP_FLAG_NO_TIMING: the engine's own per-call event pair is a diagnostic; the timed region below is bracketed by this
     #  script's events on the same stream)
     solver = mpcqp.MPCBatch(N=N, delta=delta, device=device_index, io_dtype="f32", precision=args.precision,
@@ -252,7 +256,7 @@ def main():
             "dtype": {"f32": "f32", "mixed": "f32 tiles + f64 residuals", "f64": "f64"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "configs[2]: batch=4096/GPU mixed gaits (trot/pronk/amble/gallop) + mu sweep, horizon=10, "
-                                   "dt=0.03, Lite3 constants, alpha=1e-2, euler", "batch_per_gpu": B, "horizon": N,
+                                   "dt=0.03, Lite3 constants, alpha=1e-2, euler", "batch_per_gpu": B, "shards": "distinct (seed + rank)" if args.distinct_shards else "every rank solves the configured batch", "horizon": N,
                        "precision": args.precision, "admm_block": int(solver.cfg.check_every), "max_iter": int(solver.cfg.max_iter),
                        "polish": bool(solver.cfg.flags & 1), "allgather": bool(gathered is not None),
                        "solved_fraction": solved, "admm_iters_mean": k_mean, "polish_steps_mean": float((iters // 1000).mean())},
