@@ -495,6 +495,8 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   // chosen on batches of other seeds than the bench's (tools/adapt_sweep.py).
   d.adapt_thr = cfg->precision == MPCQP_PREC_F64 ? 15.f : (cfg->N > 10 ? 10.f : 6.f);
   if (const char* ev = getenv("MPCQP_ADAPT_THR")) { const double v = atof(ev); if (v > 0) d.adapt_thr = (float)v; }     // developer knob
+  d.incr_legs = MPCQP_W_INCR_LEGS;
+  if (const char* ev = getenv("MPCQP_INCR_LEGS")) { const int v = atoi(ev); if (v >= 0 && v <= MPCQP_W_INCR_LEGS) d.incr_legs = v; }   // developer knob (0: rebuild always)
 
   // coefficient tables: c0[j][j'] = delta^2 (N - max(j,j')),
   // c1[j][j'] = delta^4 sum_{k > max(j,j')}^{N} (k-1-j+theta)(k-1-j'+theta)

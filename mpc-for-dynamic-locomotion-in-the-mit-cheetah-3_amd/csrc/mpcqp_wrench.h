@@ -984,7 +984,7 @@ __device__ __forceinline__ int w_polish_rule(const SmemW<TV, N>& s, const int L,
 // and MPCQP_W_INCR_STEPS updates in a row; a candidate from a drifted inverse would simply fail the KKT test.
 template <typename TV, typename TP, int N>
 __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tabs, const TP* __restrict__ kinvT, const int tid0,
-                                              const int budget, const bool last, const int trace_tag) {
+                                              const int budget, const bool last, const int trace_tag, const int incr_legs) {
   constexpr int NL = WG<N>::NL, NW = WG<N>::NW, G = WG<N>::G;
   constexpr int STG = 2 * 21 + 1;   // staging record of a changed leg-stage in s.E: removed | added {A[3][6], weight[3]}, stage index
   static_assert(STG * MPCQP_W_INCR_LEGS <= N * 36, "the staging records share the bytes of E");
@@ -1171,7 +1171,7 @@ __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tab
               slot += w < (L >> 5) ? __builtin_popcount(m) : (w == (L >> 5) ? __builtin_popcount(m & ((1u << (L & 31)) - 1u)) : 0);
             }
           }
-          incr = in_row < MPCQP_W_INCR_STEPS && nupd <= MPCQP_W_INCR_LEGS;
+          incr = in_row < MPCQP_W_INCR_STEPS && nupd <= incr_legs;
           if (incr && chg) {
             TP* rec = E + STG * slot;
             LegSys<TP> Lo;
@@ -1400,7 +1400,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
 #else
       const int trace_tag = -1;
 #endif
-      if (budget > 0) ok = __builtin_amdgcn_readfirstlane(w_polish_round<TV, TP, N>(s, tabs, kinvP, tid0, budget, last, trace_tag));
+      if (budget > 0) ok = __builtin_amdgcn_readfirstlane(w_polish_round<TV, TP, N>(s, tabs, kinvP, tid0, budget, last, trace_tag, cfg.incr_legs));
       if (ok == 1 && s.alpha > s.alpha_target) {   // next continuation level, from this optimum and its multipliers
         const int tid = fresh_tid<NW>(tid0);
         for (int i = tid; i < n; i += NT) s.ua[i] = s.uv[i];            // the last accepted answer and its multipliers (the ADMM
