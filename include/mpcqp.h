@@ -52,7 +52,8 @@ extern "C" {
 #define MPCQP_DTYPE_F64 1
 
 /* arithmetic of the engine (product library; the oracle is always all-f64) */
-#define MPCQP_PREC_F32 0   /* matrix tiles and vectors in f32 */
+#define MPCQP_PREC_F32 0   /* matrix tiles and vectors in f32 (GRFs within 2e-2; at N = 20 that band does not hold and the product
+                              library serves the request with MIXED) */
 #define MPCQP_PREC_MIXED 1 /* matrix tiles f32; structured residuals, refinement and duals in f64 */
 #define MPCQP_PREC_F64 2   /* everything f64 */
 

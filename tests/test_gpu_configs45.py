@@ -166,3 +166,14 @@ def test_one_rank_rccl_bench_rehearsal():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["config"]["allgather"] is True and j["config"]["solved_fraction"] >= 0.999
     assert abs(j["value"] - 4096 * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]
+
+
+def test_f32_request_at_horizon20_is_served_with_mixed(oracle_solve):
+    """All-fp32 arithmetic does not hold its 2e-2 band at N = 20; the product library serves PREC_F32 there with the MIXED arithmetic."""
+    b = mpcqp.synth.config5(256)
+    ref = oracle_solve(b, N=20)
+    out = gpu_solve(b, N=20, io="f32", precision="f32")
+    mix = gpu_solve(b, N=20, io="f32", precision="mixed")
+    assert np.array_equal(out["u"], mix["u"]) and np.array_equal(out["status"], mix["status"])
+    ok = solved(out["status"])
+    assert ok.mean() >= 0.99 and rel_err(out["u"], ref["u"])[ok].max() <= 1e-4
