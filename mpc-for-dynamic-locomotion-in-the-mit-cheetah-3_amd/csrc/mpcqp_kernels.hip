@@ -495,6 +495,12 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   // chosen on batches of other seeds than the bench's (tools/adapt_sweep.py).
   d.adapt_thr = cfg->precision == MPCQP_PREC_F64 ? 15.f : (cfg->N > 10 ? 10.f : 6.f);
   if (const char* ev = getenv("MPCQP_ADAPT_THR")) { const double v = atof(ev); if (v > 0) d.adapt_thr = (float)v; }     // developer knob
+  // A cold solve's first ADMM block is 0.7 check_every long: most QPs have their active set by then (mean iterations 114 -> 82 at
+  // N = 10, B = 65 536: 14.6 -> 16.2 M QP/s, N = 20: +10 %), the others go on in full blocks; at B = 4096, where the launch is as
+  // long as its hardest QPs, neutral (eight batches of other seeds, tools/adapt_sweep.py).  With the polish only: an ADMM-only
+  // run keeps OSQP's uniform check interval.
+  d.first_block = (cfg->flags & MPCQP_FLAG_POLISH) ? (7 * cfg->check_every) / 10 : 0;
+  if (const char* ev = getenv("MPCQP_FIRST_BLOCK")) { const int v = atoi(ev); if (v >= 0) d.first_block = v; }   // developer knob (0: check_every)
   d.incr_legs = MPCQP_W_INCR_LEGS;
   if (const char* ev = getenv("MPCQP_INCR_LEGS")) { const int v = atoi(ev); if (v >= 0 && v <= MPCQP_W_INCR_LEGS) d.incr_legs = v; }   // developer knob (0: rebuild always)
 

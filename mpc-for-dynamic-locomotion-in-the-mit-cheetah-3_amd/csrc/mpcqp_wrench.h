@@ -798,6 +798,7 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
   TM* const cv = reinterpret_cast<TM*>(s.cv);
   float rho = s.rho;
   int K = kfirst > 0 ? min(kfirst, cfg.check_every) : cfg.check_every;
+  K = max(1, min(K, cfg.max_iter - __builtin_amdgcn_readfirstlane(s.iters)));   // (the iteration cap is exact)
   int it = 0, seg_end = (adapt && MPCQP_W_ADAPT_AT < K) ? MPCQP_W_ADAPT_AT : K;
   int hard = 0;
   float ratio = 0.f;
@@ -896,7 +897,7 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
     }
     rho = fminf(rho * ratio, ADAPT_RHO_MAX);   // ... and a longer block
     hard = 1;
-    K = min(HARD_ITER_FACTOR * K, cfg.max_iter);
+    K = max(K, min(HARD_ITER_FACTOR * K, cfg.max_iter - __builtin_amdgcn_readfirstlane(s.iters)));
     seg_end = K;
   }
   if (fresh_tid<NW>(tid0) == 0) { s.rho = rho; s.iters += K; s.hard |= hard; }
@@ -1388,7 +1389,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       int budget = kind == R_WARM ? min(warm_tries, polish_max) : 2 * polish_max;
       const bool admm_only = !(cfg.flags & MPCQP_FLAG_POLISH);
       if (kind == R_ADMM) {
-        w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, (round == 0 && warm >= 2) ? WARM_K : 0, tid0);
+        w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, round == 0 ? (warm >= 2 ? (cfg.first_block > 0 ? min(WARM_K, (6 * cfg.first_block) / 10) : WARM_K) : cfg.first_block) : 0, tid0);
         budget = admm_only ? 0 : (__builtin_amdgcn_readfirstlane(s.hard) ? HARD_POLISH_FACTOR : 1) * polish_max;
       }
       // Active-set steps while they make progress: a step that does not at least halve the KKT violation of the previous one

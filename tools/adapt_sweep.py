@@ -20,6 +20,7 @@ for name, batch in cases:
     for thr in thrs:
         os.environ["MPCQP_ADAPT_THR"] = str(thr)
         kw = {"polish_max": int(os.environ["SW_PM"])} if os.environ.get("SW_PM") else {}
+        if os.environ.get("SW_CE"): kw.update(check_every=int(os.environ["SW_CE"]), max_iter=int(os.environ.get("SW_MI", "400")))
         sol = mpcqp.MPCBatch(N=N, delta=0.03, precision=prec, **kw)
         dev = sol.upload(batch)
         ms = []
