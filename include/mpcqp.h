@@ -106,7 +106,9 @@ typedef struct MpcQpConfig {
   double relax;         /* over-relaxation in (0,2) */
   int32_t max_iter;     /* ADMM iteration cap K */
   int32_t check_every;  /* ADMM block length between polish attempts (iterations); default 100, tuned for N = 10 --
-                           scale both with N / 10 for other horizons (200 / 800 at N = 20), as the Python host layer does */
+                           scale both with N / 10 for other horizons (200 / 800 at N = 20), as the Python host layer does.
+                           With MPCQP_FLAG_POLISH a cold solve's first block is 0.7 check_every long (most QPs have their active
+                           set by then); ADMM-only runs test termination every check_every iterations, as OSQP does */
   double eps_abs, eps_rel;
   int32_t polish_max;   /* active-set refinement steps per polish attempt */
   int32_t device;       /* HIP device ordinal (product library) */
