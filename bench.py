@@ -27,7 +27,7 @@ import mpcqp  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0        # HBM3E spec (6290 measured float4 copy)
-TRAFFIC_FILE = "r02_f_hbm_traffic.json"   # PMC passes of the current kernel (profiles/)
+TRAFFIC_FILE = "r02_g_hbm_traffic.json"   # PMC passes of the current kernel (profiles/)
 
 
 def algorithmic_flops(N, K):
