@@ -28,6 +28,8 @@ import mpcqp  # noqa: E402
 PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0        # HBM3E spec (6290 measured float4 copy)
 TRAFFIC_FILE = "r02_g_hbm_traffic.json"   # PMC passes of the current kernel (profiles/)
+SQ_FILE = "r02_g_pmc.txt"                   # SQ counter passes of the same kernel and workload (tools/pmc_run.sh)
+PEAK_VALU_ISSUE = 1024 * 2.4e9 / 4          # wave-instructions/s: 1024 SIMDs, one wave64 vector instruction per 4 cycles (an fp64 FMA: 8)
 
 
 def algorithmic_flops(N, K):
@@ -248,6 +250,21 @@ def main():
                 traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/" + TRAFFIC_FILE
         except (OSError, ValueError, KeyError):
             pass
+        # what actually binds the kernel ("Roofline that binds"): vector-instruction issue.  SQ_INSTS_VALU per
+        # launch comes from the committed counter passes (not measured in this run, like `traffic`), the duration is this run's.
+        issue = None
+        try:
+            if B == 4096 and args.precision == "mixed":
+                for ln in open(os.path.join(REPO, "profiles", SQ_FILE)):
+                    if ln.startswith("SQ_INSTS_VALU "):
+                        n_valu = float(ln.split()[-2])
+                        rate = n_valu / (kernel_ms * 1e-3)
+                        issue = {"achieved": rate / 1e9, "peak": PEAK_VALU_ISSUE / 1e9, "unit": "G wave-instructions/s", "frac": rate / PEAK_VALU_ISSUE,
+                                 "valu_instructions_per_launch": n_valu, "source": "profiles/" + SQ_FILE,
+                                 "note": "a launch of 4096 QPs ends with its longest QPs alone on their SIMDs (DESIGN.md section 5); fp64 FMAs of the polish issue at half this rate"}
+                        break
+        except (OSError, ValueError, IndexError):
+            pass
         line = {
             "metric": "QP solves/sec (horizon=10, 4-contact Lite3) at batch=4096", "value": value, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -269,7 +286,8 @@ def main():
                          "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_qp": flops,
                          "hbm": {"achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS,
-                                 "algorithmic_bytes_per_qp": algorithmic_bytes(N), "note": "non-binding roof (SURVEY 8d)"}},
+                                 "algorithmic_bytes_per_qp": algorithmic_bytes(N), "note": "non-binding roof (SURVEY 8d)"},
+                         "valu_issue": issue},
         }
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(batch, dict(N=N, delta=delta, rho=solver.cfg.rho, sigma=solver.cfg.sigma, relax=solver.cfg.relax,
