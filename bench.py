@@ -97,7 +97,7 @@ def cpu_baseline(batch, cfg_kw, sample):
                       f"relax/iteration cap as the GPU run), OpenMP over the batch, {dt:.1f} s wall; solved fraction {solved:.3f}"}
 
 
-def gait_breakdown(solver, N, delta, B, steps=5):
+def gait_breakdown(solver, N, delta, B, steps=5, precision="mixed"):
     """Secondary figures on the same engine: single-gait batches, a true 4-contact batch (all feet down on all stages), the
     headline workload drawn with other seeds, and a batch that fills the device many times over."""
     out = {}
@@ -138,6 +138,34 @@ def gait_breakdown(solver, N, delta, B, steps=5):
     torch.cuda.synchronize()
     st = o["status"].cpu().numpy()
     out["mixed_batch_65536"] = {"qp_per_s": big * 3 / (e0.elapsed_time(e1) * 1e-3), "solved_fraction": float(((st == 1) | (st == 2)).mean())}
+    # two independent batches of B in flight: two handles on two HIP streams (a handle serves one stream at a time,
+    # include/mpcqp.h).  The tail of one launch is filled by the head of the other -- what a caller with more than one fleet gets per
+    # batch of B.  NOT `value`: that is one batch per step on one stream.
+    try:
+        sols = [solver, mpcqp.MPCBatch(N=N, delta=delta, device=solver.device.index, io_dtype="f32", precision=precision,
+                                       flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)]
+        devs = [s_.upload(mpcqp.synth.make_batch(B, N, delta, 20250809 + i, allg, (0.3, 0.5, 0.7, 1.0))) for i, s_ in enumerate(sols)]
+        streams = [torch.cuda.Stream(device=solver.device) for _ in range(2)]
+        torch.cuda.synchronize()
+        reps = 4 * steps
+
+        def both():
+            for s_, d, st_ in zip(sols, devs, streams):
+                o_ = s_.solve_batch(d["x0"], d["r"], d["contact"], d["xdes"], d["mu"], want_X=False, stream=st_)
+            return o_
+        for _ in range(3):
+            both()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o = both()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        st = o["status"].cpu().numpy()
+        out["two_batches_two_streams"] = {"qp_per_s": 2 * B * reps / dt2, "solved_fraction": float(((st == 1) | (st == 2)).mean()),
+                                          "note": "secondary: two handles / two HIP streams, wall clock over both; not the headline"}
+    except Exception as e:   # a secondary figure must not take the bench line down
+        out["two_batches_two_streams"] = {"error": repr(e)}
     return out
 
 
@@ -298,7 +326,7 @@ def main():
             if cb:
                 line["cpu_baseline"] = cb
         if world == 1 and not args.no_breakdown:
-            line["breakdown"] = gait_breakdown(solver, N, delta, B)
+            line["breakdown"] = gait_breakdown(solver, N, delta, B, precision=args.precision)
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()
