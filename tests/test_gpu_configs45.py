@@ -177,3 +177,27 @@ def test_f32_request_at_horizon20_is_served_with_mixed(oracle_solve):
     assert np.array_equal(out["u"], mix["u"]) and np.array_equal(out["status"], mix["status"])
     ok = solved(out["status"])
     assert ok.mean() >= 0.99 and rel_err(out["u"], ref["u"])[ok].max() <= 1e-4
+
+
+def test_two_handles_on_two_streams_give_the_serial_bits():
+    """include/mpcqp.h, "Handles and devices": a handle serves one stream at a time, two concurrent streams need two handles.
+    Two handles solving different batches concurrently (their launches overlap on the device: ordered launch form, per-handle
+    queue heads and workspaces) return the bits each returns alone."""
+    G, M = ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0)
+    sols = [mpcqp.MPCBatch(N=10, delta=0.03, io_dtype="f32", precision="mixed") for _ in range(2)]
+    devs = [s.upload(mpcqp.synth.make_batch(4096, 10, 0.03, 31 + i, G, M)) for i, s in enumerate(sols)]
+    run = lambda i, st=None: sols[i].solve_batch(devs[i]["x0"], devs[i]["r"], devs[i]["contact"], devs[i]["xdes"], devs[i]["mu"], stream=st)
+    alone = []
+    for i in range(2):
+        o = run(i)
+        torch.cuda.synchronize()
+        alone.append({k: o[k].clone() for k in ("u", "status", "iters")})
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    for _ in range(5):
+        outs = [run(i, streams[i]) for i in range(2)]
+    torch.cuda.synchronize()
+    for i in range(2):
+        for k in ("u", "status", "iters"):
+            assert torch.equal(outs[i][k], alone[i][k]), (i, k)
+    assert not torch.equal(alone[0]["u"], alone[1]["u"])
