@@ -339,5 +339,6 @@ def kkt_report(H, g, G, lo, hi, u, y):
     yp, ym = np.maximum(y, 0.0), np.minimum(y, 0.0)
     fin_hi = np.isfinite(hi); fin_lo = np.isfinite(lo)
     dual_sign = float(max(np.max(np.where(fin_hi, 0.0, yp)), np.max(np.where(fin_lo, 0.0, -ym))))
-    comp = float(max(np.max(np.where(fin_hi, yp * (hi - Gu), 0.0)), np.max(np.where(fin_lo, -ym * (Gu - lo), 0.0))))
+    hi_f, lo_f = np.where(fin_hi, hi, Gu), np.where(fin_lo, lo, Gu)      # (an infinite bound has no complementarity term: no 0 * inf)
+    comp = float(max(np.max(yp * (hi_f - Gu)), np.max(-ym * (Gu - lo_f))))
     return {"stationarity": stat, "primal": prim, "dual_sign": dual_sign, "complementarity": comp}
