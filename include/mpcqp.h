@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_VERSION 0x00010000 /* 1.0.0 */
+#define MPCQP_VERSION 0x00010100 /* 1.1.0: horizons up to 64 (stage-wise engine), tuning fields in MpcQpConfig */
 
 /* return codes */
 #define MPCQP_OK 0
@@ -112,6 +112,15 @@ typedef struct MpcQpConfig {
   double eps_abs, eps_rel;
   int32_t polish_max;   /* active-set refinement steps per polish attempt */
   int32_t device;       /* HIP device ordinal (product library) */
+  /* Engine tuning (product library; the checker ignores them).  0 = the engine's own default, which is what the benchmark runs
+     with; none of them changes a result beyond rounding except alpha_floor.  They exist for the measurement scripts under tools/
+     and for the tests that compare a mechanism with its fallback -- the library reads no environment variables. */
+  int32_t first_block;  /* iterations of a cold solve's first ADMM block; 0: 0.7 check_every (ADMM-only runs: check_every); -1: check_every */
+  int32_t incr_legs;    /* changed leg-stages up to which a polish step updates S^-1 instead of rebuilding it; 0: 8; -1: always rebuild */
+  int32_t listed_max;   /* device-fills up to which an ordered launch is one workgroup per QP (beyond: resident workgroups on a queue);
+                           0: 4; -1: always queued */
+  float adapt_thr;      /* residual ratio at the early rho check beyond which a QP gets a larger penalty and a longer block; 0: per precision */
+  double alpha_floor;   /* where the regulariser continuation of an alpha = 0 request ends; 0: 3e-6 */
 } MpcQpConfig;
 
 typedef struct mpcqp_engine* mpcqp_handle;
@@ -189,7 +198,9 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
  *   ref      T  [B,10]     in/out: roll0, pitch0, yaw_start, com_pos_start[3], v_com_ref[3], theta_dot (as mpcqp_solve_batch_gait)
  *   plan_pos T  [B,S,4,3]  plan[step]['pos'] of all S steps (stance feet stand on the plan; swing feet carry no force)
  *   plan_feet_id u8 [B,S,4]  plan[step]['feet_id']
- *   plan_meta i32[B,4]     S_b (steps of this robot's plan, <= S), ss_duration, ds_duration, reserved (0)
+ *   plan_meta i32[B,4]     S_b (steps of this robot's plan, 1 <= S_b <= S), ss_duration (>= 0), ds_duration (>= 0, ss + ds >= 1),
+ *                          reserved (0).  The table is read on the device, where the host cannot validate it: values outside
+ *                          these ranges (and negative ticks) are clamped into them, never used as indices or divisors.
  *   tick     i32[B]        in/out: control tick of each robot (advanced by T)
  *   mu       T  [B]
  *   actual / desired / forces  T [B,T,12], each may be NULL: the log's TRACKING PERFORMANCE actual / desired rows and the

@@ -38,6 +38,7 @@ class MpcQpConfig(ctypes.Structure):
         ("precision", c_int32), ("flags", c_uint32), ("rho", c_double), ("sigma", c_double),
         ("relax", c_double), ("max_iter", c_int32), ("check_every", c_int32),
         ("eps_abs", c_double), ("eps_rel", c_double), ("polish_max", c_int32), ("device", c_int32),
+        ("first_block", c_int32), ("incr_legs", c_int32), ("listed_max", c_int32), ("adapt_thr", c_float), ("alpha_floor", c_double),
     ]
 
     def as_dict(self):

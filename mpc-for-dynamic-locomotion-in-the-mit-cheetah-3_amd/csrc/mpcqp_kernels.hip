@@ -104,8 +104,11 @@ mpcqp_rollout_expand_kernel(const TIO* __restrict__ x, const TIO* __restrict__ r
   const int64_t b = t / per;
   const int e = (int)(t - b * per);
   const TIO* rf = ref + b * 10;
-  const int S = plan.meta[b * 4 + 0], ss = plan.meta[b * 4 + 1], ds = plan.meta[b * 4 + 2], t0 = tick[b];
-  const int step0 = min(t0 / (ss + ds), S - 1);
+  // (the plan table lives in device memory the host cannot inspect: malformed rows are clamped, never indexed with --
+  //  1 <= S_b <= S, ss >= 0, ss + ds >= 1, tick >= 0; include/mpcqp.h)
+  const int S = min(max(plan.meta[b * 4 + 0], 1), Smax), ss = max(plan.meta[b * 4 + 1], 0), period = max(ss + max(plan.meta[b * 4 + 2], 0), 1);
+  const int t0 = max(tick[b], 0);
+  const int step0 = min(t0 / period, S - 1);
   const double gate = step0 == S - 1 ? 0.0 : 1.0;              // src/mpc.py:181-183: references zeroed on the last plan step
   if (e < nx) {
     const int k = e / 13, c = e % 13;
@@ -120,7 +123,7 @@ mpcqp_rollout_expand_kernel(const TIO* __restrict__ x, const TIO* __restrict__ r
     xdes[b * nx + e] = (TIO)v;
   } else {
     const int i = e - nx, k = i / 12, l = (i % 12) / 3, a = i % 3;
-    const int tau = t0 + k, si = min(tau / (ss + ds), S - 1), tin = tau - si * (ss + ds);   // past the plan: the last step, all stance
+    const int tau = t0 + k, si = min(tau / period, S - 1), tin = tau - si * period;   // past the plan: the last step, all stance
     const TIO* pos = (const TIO*)plan.pos + ((b * Smax + si) * 4 + l) * 3;
     const double com = k == 0 ? (double)x[b * 13 + 3 + a] : (double)rf[3 + a] + (double)k * d * gate * (double)rf[6 + a];
     r[b * nr + i] = (TIO)((double)pos[a] - com);
@@ -132,13 +135,14 @@ template <typename TIO>
 __global__ void __launch_bounds__(256)
 mpcqp_rollout_advance_kernel(TIO* __restrict__ x, TIO* __restrict__ ref, const RolloutPlan plan, int32_t* __restrict__ tick, const TIO* __restrict__ X,
                              const TIO* __restrict__ u, const int32_t* __restrict__ status, const double d, const int N, const int64_t B,
-                             const int T, const int it, TIO* __restrict__ actual, TIO* __restrict__ desired, TIO* __restrict__ forces,
+                             const int T, const int it, const int Smax, TIO* __restrict__ actual, TIO* __restrict__ desired, TIO* __restrict__ forces,
                              int32_t* __restrict__ solved) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   TIO* rf = ref + b * 10;
-  const int S = plan.meta[b * 4 + 0], ss = plan.meta[b * 4 + 1], ds = plan.meta[b * 4 + 2], t0 = tick[b];
-  const double gate = min(t0 / (ss + ds), S - 1) == S - 1 ? 0.0 : 1.0;
+  const int S = min(max(plan.meta[b * 4 + 0], 1), Smax), ss = max(plan.meta[b * 4 + 1], 0), period = max(ss + max(plan.meta[b * 4 + 2], 0), 1);
+  const int t0 = max(tick[b], 0);
+  const double gate = min(t0 / period, S - 1) == S - 1 ? 0.0 : 1.0;
   const size_t row = ((size_t)b * T + it) * 12;
   if (actual) for (int c = 0; c < 12; ++c) actual[row + c] = x[b * 13 + c];                      // logger.log_tracking_data (src/mpc.py:295)
   if (desired) {
@@ -152,7 +156,7 @@ mpcqp_rollout_advance_kernel(TIO* __restrict__ x, TIO* __restrict__ ref, const R
   for (int c = 0; c < 12; ++c) x[b * 13 + c] = X[((size_t)b * (N + 1) + 1) * 13 + c];          // the world step: the model's own prediction
   for (int a = 0; a < 3; ++a) rf[3 + a] = (TIO)((double)rf[3 + a] + gate * (double)rf[6 + a] * d);   // src/mpc.py:261
   rf[2] = (TIO)((double)rf[2] + gate * (double)rf[9] * d);                                      // src/mpc.py:262
-  tick[b] = t0 + 1;
+  tick[b] = tick[b] + 1;
 }
 
 }  // namespace
@@ -170,6 +174,7 @@ struct mpcqp_engine {
   int order_phase = 0;        // which header set the next ordered launch counts into
   int order_cap = 0;
   int slots = 0;              // workgroups the device holds at once (2 per CU)
+  int listed_max = 4;         // device-fills up to which an ordered launch is one workgroup per QP (MpcQpConfig.listed_max)
   double* wr_K = nullptr;     // wrench-space engine (mpcqp_wrench.h): K_q [6][N][N], K^-1 in tile layout (fp32 / fp64)
   float* wr_kinv32 = nullptr;
   double* wr_kinv64 = nullptr;
@@ -256,8 +261,7 @@ hipError_t launch_wrench(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void
       // Up to a few device-fills the hardware's own dispatcher does better with the ordered list than resident workgroups on an
       // atomic queue (B = 4096: 0.53-0.56 ms against 0.60-0.63, tools/order_study.py): a resident wave stays on the SIMD it
       // started on, next to whatever partner it was given, while a fresh workgroup goes where there is room.
-      static const int64_t listed_max = getenv("MPCQP_LISTED_MAX") ? atoll(getenv("MPCQP_LISTED_MAX")) : 4;   // developer knob (device-fills)
-      if (B <= listed_max * slots) ob.head = nullptr;
+      if (B <= (int64_t)e->listed_max * slots) ob.head = nullptr;
       else grid = dim3((unsigned)slots);
     }
   }
@@ -488,21 +492,19 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   d.theta = cfg->disc == MPCQP_DISC_ZOH ? 0.5 : 0.0;
   d.max_iter = cfg->max_iter; d.check_every = cfg->check_every; d.polish_max = cfg->polish_max;
   d.flags = cfg->flags;
-  d.alpha_floor = ALPHA_FLOOR;
-  if (const char* ev = getenv("MPCQP_ALPHA_FLOOR")) { const double v = atof(ev); if (v > 0) d.alpha_floor = v; }   // developer knob
+  // Engine tuning fields of the configuration (0 = default; include/mpcqp.h).  The library reads no environment variables.
+  d.alpha_floor = cfg->alpha_floor > 0 ? cfg->alpha_floor : ALPHA_FLOOR;
   // Early rho check (wrench engine): the ratio beyond which a QP is given a larger penalty and a longer block.  The all-fp64 ADMM
   // sees a clean dual residual and larger ratios than the fp32-tile one, whose dual residual carries the solve's rounding noise;
   // chosen on batches of other seeds than the bench's (tools/adapt_sweep.py).
-  d.adapt_thr = cfg->precision == MPCQP_PREC_F64 ? 15.f : (cfg->N > 10 ? 10.f : 6.f);
-  if (const char* ev = getenv("MPCQP_ADAPT_THR")) { const double v = atof(ev); if (v > 0) d.adapt_thr = (float)v; }     // developer knob
+  d.adapt_thr = cfg->adapt_thr > 0 ? cfg->adapt_thr : (cfg->precision == MPCQP_PREC_F64 ? 15.f : (cfg->N > 10 ? 10.f : 6.f));
   // A cold solve's first ADMM block is 0.7 check_every long: most QPs have their active set by then (mean iterations 114 -> 82 at
   // N = 10, B = 65 536: 14.6 -> 16.2 M QP/s, N = 20: +10 %), the others go on in full blocks; at B = 4096, where the launch is as
   // long as its hardest QPs, neutral (eight batches of other seeds, tools/adapt_sweep.py).  With the polish only: an ADMM-only
   // run keeps OSQP's uniform check interval.
-  d.first_block = (cfg->flags & MPCQP_FLAG_POLISH) ? (7 * cfg->check_every) / 10 : 0;
-  if (const char* ev = getenv("MPCQP_FIRST_BLOCK")) { const int v = atoi(ev); if (v >= 0) d.first_block = v; }   // developer knob (0: check_every)
-  d.incr_legs = MPCQP_W_INCR_LEGS;
-  if (const char* ev = getenv("MPCQP_INCR_LEGS")) { const int v = atoi(ev); if (v >= 0 && v <= MPCQP_W_INCR_LEGS) d.incr_legs = v; }   // developer knob (0: rebuild always)
+  d.first_block = cfg->first_block > 0 ? cfg->first_block : (cfg->first_block < 0 ? 0 : ((cfg->flags & MPCQP_FLAG_POLISH) ? (7 * cfg->check_every) / 10 : 0));
+  d.incr_legs = cfg->incr_legs > 0 ? (cfg->incr_legs < MPCQP_W_INCR_LEGS ? cfg->incr_legs : MPCQP_W_INCR_LEGS) : (cfg->incr_legs < 0 ? 0 : MPCQP_W_INCR_LEGS);
+  e->listed_max = cfg->listed_max > 0 ? cfg->listed_max : (cfg->listed_max < 0 ? 0 : 4);
 
   // coefficient tables: c0[j][j'] = delta^2 (N - max(j,j')),
   // c1[j][j'] = delta^4 sum_{k > max(j,j')}^{N} (k-1-j+theta)(k-1-j'+theta)
@@ -688,10 +690,10 @@ int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* x, void
     if (rc != MPCQP_OK) return rc;
     if (el == 8)
       hipLaunchKernelGGL((mpcqp_rollout_advance_kernel<double>), ga, dim3(256), 0, st, (double*)x, (double*)ref, plan, tick, (const double*)X,
-                         (const double*)u, status, h->cfg.delta, (int)N, B, (int)T, it, (double*)actual, (double*)desired, (double*)forces, solved);
+                         (const double*)u, status, h->cfg.delta, (int)N, B, (int)T, it, (int)S, (double*)actual, (double*)desired, (double*)forces, solved);
     else
       hipLaunchKernelGGL((mpcqp_rollout_advance_kernel<float>), ga, dim3(256), 0, st, (float*)x, (float*)ref, plan, tick, (const float*)X,
-                         (const float*)u, status, h->cfg.delta, (int)N, B, (int)T, it, (float*)actual, (float*)desired, (float*)forces, solved);
+                         (const float*)u, status, h->cfg.delta, (int)N, B, (int)T, it, (int)S, (float*)actual, (float*)desired, (float*)forces, solved);
     const hipError_t he = hipGetLastError();
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "roll-out kernel launch", he);
   }

@@ -237,7 +237,7 @@ __device__ __forceinline__ void tilemv(const WTile<double>& t, const double (&x)
 // a full tile-layout table (16 / 32 KB per load, every lane 16 x 16 B) misses L1 for every wave of the CU and its loads
 // queued for ~30 k cycles at full occupancy (the miss queue of the L1, not bandwidth: phase stamps).
 // Pass 2 adds E: entry (R, C) of stage j = R / 6 sits at E[6 R + C - 6 j] and exists iff 0 <= C - 6 j < 6, i.e. for tile
-// column c iff (c - lo) <u 6 with lo = 6 j - 8 gc per tile row; reads outside a row's run are masked (LDS reads never fault).
+// column c iff (c - lo) <u 6 with lo = 6 j - 8 gc per tile row; outside a row's run the index is clamped to 0 and the value masked.
 template <typename TM, int N>
 __device__ __forceinline__ void w_tile_init(WTile<TM>& t, const TM* __restrict__ kq, const TM* __restrict__ E, int gr, int gc, int tid) {
   constexpr int NT = WG<N>::NT, NQ = WG<N>::NQ;
@@ -272,11 +272,11 @@ __device__ __forceinline__ void w_tile_init(WTile<TM>& t, const TM* __restrict__
   for (int r = 0; r < 8; ++r) {
     const int R = 8 * gr + r, jR = (R * 43) >> 8;            // R / 6 for R < 128
     const int lo = 6 * jR - 8 * gc;
-    const int base = R < NQ ? 6 * R - lo : -(1 << 20);         // rows of the padding read nothing
+    const int base = R < NQ ? 6 * R - lo : 0;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const bool in = (unsigned)(c - lo) < 6u && R < NQ;
-      const TM e = E[base + c];
+      const TM e = E[in ? base + c : 0];                       // (index clamped, value masked: no address outside E is ever formed)
       tset(t, r, c, tget(t, r, c) + (in ? e : (TM)0));
     }
   }

@@ -52,18 +52,21 @@ class MPCBatch:
         return {"x0": f(batch["x0"]), "r": f(batch["r"]), "xdes": f(batch["xdes"]), "mu": f(batch["mu"]),
                 "contact": torch.as_tensor(np.ascontiguousarray(batch["contact"], dtype=np.uint8)).to(self.device).contiguous()}
 
-    def _outputs(self, B, want_X):
+    def _outputs(self, B, want_X, st=None):
         torch = _torch()
         key = (B, want_X)
         if key not in self._out:   # allocated once per batch size, reused afterwards
             N = self.N
-            self._out[key] = {
-                "u": torch.zeros((B, N, 12), dtype=self.tdtype, device=self.device),   # zeros = "no guess" for a warm-started engine
-                "X": torch.empty((B, N + 1, 13), dtype=self.tdtype, device=self.device) if want_X else None,
-                "status": torch.empty(B, dtype=torch.int32, device=self.device),
-                "iters": torch.empty(B, dtype=torch.int32, device=self.device),
-                "res": torch.empty((B, 2), dtype=torch.float32, device=self.device),
-            }
+            # The zero fill below is a kernel on torch's CURRENT stream; the solve that reads the buffer (warm start) or writes it runs
+            # on `st`, which may be a non-blocking side stream that nothing orders after it: fill on `st` itself.
+            with torch.cuda.stream(st if st is not None else torch.cuda.current_stream(self.device)):
+                self._out[key] = {
+                    "u": torch.zeros((B, N, 12), dtype=self.tdtype, device=self.device),   # zeros = "no guess" for a warm-started engine
+                    "X": torch.empty((B, N + 1, 13), dtype=self.tdtype, device=self.device) if want_X else None,
+                    "status": torch.empty(B, dtype=torch.int32, device=self.device),
+                    "iters": torch.empty(B, dtype=torch.int32, device=self.device),
+                    "res": torch.empty((B, 2), dtype=torch.float32, device=self.device),
+                }
         return self._out[key]
 
     def _seed(self, out, u_init, st):
@@ -87,8 +90,8 @@ class MPCBatch:
             if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
                 raise ValueError(f"operand mismatch: expected {shape} {dt} contiguous on {self.device}, got "
                                  f"{tuple(t.shape)} {t.dtype} on {t.device}")
-        out = self._outputs(B, want_X)
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        out = self._outputs(B, want_X, st)
         self._seed(out, u_init, st)
         self.engine.solve_batch_ptr(B, x0.data_ptr(), r.data_ptr(), contact.data_ptr(), xdes.data_ptr(), mu.data_ptr(),
                                     out["u"].data_ptr(), out["X"].data_ptr() if want_X else None, out["status"].data_ptr(),
@@ -114,8 +117,8 @@ class MPCBatch:
             if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
                 raise ValueError(f"operand mismatch: expected {shape} {dt} contiguous on {self.device}, got "
                                  f"{tuple(t.shape)} {t.dtype} on {t.device}")
-        out = self._outputs(B, want_X)
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        out = self._outputs(B, want_X, st)
         self._seed(out, u_init, st)
         self.engine.solve_batch_gait_ptr(B, x0.data_ptr(), ref.data_ptr(), feet0.data_ptr(), footholds.data_ptr(), gait.data_ptr(),
                                          feet_id.data_ptr(), mu.data_ptr(), out["u"].data_ptr(),
@@ -136,8 +139,9 @@ class MPCBatch:
                 raise ValueError(f"operand mismatch: expected {shape} {dt} contiguous on {self.device}, got {tuple(t.shape)} {t.dtype} on {t.device}")
         mk = lambda: torch.empty((B, T, 12), dtype=self.tdtype, device=self.device) if log else None
         actual, desired, forces = mk(), mk(), mk()
-        solved = torch.zeros(B, dtype=torch.int32, device=self.device)
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        # (the advance kernel initialises `solved` at the first tick, on `st`; a zero fill here would run on torch's current stream)
+        solved = (torch.empty if T > 0 else torch.zeros)(B, dtype=torch.int32, device=self.device)
         p = lambda t: t.data_ptr() if t is not None else None
         self.engine.rollout_ptr(B, T, S, x.data_ptr(), ref.data_ptr(), plan_pos.data_ptr(), plan_feet_id.data_ptr(), plan_meta.data_ptr(),
                                 tick.data_ptr(), mu.data_ptr(), p(actual), p(desired), p(forces), solved.data_ptr(), st.cuda_stream)

@@ -701,8 +701,11 @@ int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* xv, voi
   for (int it = 0; it < T && rc == MPCQP_OK; it++) {
     for (int64_t b = 0; b < B; b++) {
       const double* rf = ref + b * 10;
-      const int Sb = plan_meta[b * 4], ss = plan_meta[b * 4 + 1], ds = plan_meta[b * 4 + 2], t0 = tick[b];
-      int step0 = t0 / (ss + ds); if (step0 > Sb - 1) step0 = Sb - 1;
+      /* malformed plan rows are clamped, never indexed with: 1 <= S_b <= S, ss >= 0, ss + ds >= 1, tick >= 0 (include/mpcqp.h) */
+      const int Sb = plan_meta[b * 4] < 1 ? 1 : (plan_meta[b * 4] > S ? S : plan_meta[b * 4]);
+      const int ss = plan_meta[b * 4 + 1] < 0 ? 0 : plan_meta[b * 4 + 1], per = (ss + (plan_meta[b * 4 + 2] < 0 ? 0 : plan_meta[b * 4 + 2])) < 1 ? 1 : ss + (plan_meta[b * 4 + 2] < 0 ? 0 : plan_meta[b * 4 + 2]);
+      const int t0 = tick[b] < 0 ? 0 : tick[b];
+      int step0 = t0 / per; if (step0 > Sb - 1) step0 = Sb - 1;
       const double gate = step0 == Sb - 1 ? 0.0 : 1.0;                                        /* src/mpc.py:181-183 */
       for (int k = 0; k <= N; k++) {                                                           /* src/mpc.py:202-214 */
         double* xk = xd + (b * (N + 1) + k) * NX;
@@ -715,8 +718,8 @@ int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* xv, voi
       }
       for (int k = 0; k < N; k++) {
         const int tau = t0 + k;
-        int si = tau / (ss + ds); if (si > Sb - 1) si = Sb - 1;
-        const int tin = tau - si * (ss + ds);
+        int si = tau / per; if (si > Sb - 1) si = Sb - 1;
+        const int tin = tau - si * per;
         for (int l = 0; l < 4; l++) {
           ct[(b * N + k) * 4 + l] = (tin < ss) ? (plan_feet_id[(b * S + si) * 4 + l] ? 1 : 0) : 1;   /* footstep_planner.py:239-246 */
           for (int a = 0; a < 3; a++)                                                          /* src/mpc.py:218-239 */
@@ -728,8 +731,10 @@ int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* xv, voi
     if (rc != MPCQP_OK) break;
     for (int64_t b = 0; b < B; b++) {
       double* rf = ref + b * 10;
-      const int Sb = plan_meta[b * 4], ss = plan_meta[b * 4 + 1], ds = plan_meta[b * 4 + 2], t0 = tick[b];
-      int step0 = t0 / (ss + ds); if (step0 > Sb - 1) step0 = Sb - 1;
+      const int Sb = plan_meta[b * 4] < 1 ? 1 : (plan_meta[b * 4] > S ? S : plan_meta[b * 4]);
+      const int ss = plan_meta[b * 4 + 1] < 0 ? 0 : plan_meta[b * 4 + 1], per = (ss + (plan_meta[b * 4 + 2] < 0 ? 0 : plan_meta[b * 4 + 2])) < 1 ? 1 : ss + (plan_meta[b * 4 + 2] < 0 ? 0 : plan_meta[b * 4 + 2]);
+      const int t0 = tick[b] < 0 ? 0 : tick[b];
+      int step0 = t0 / per; if (step0 > Sb - 1) step0 = Sb - 1;
       const double gate = step0 == Sb - 1 ? 0.0 : 1.0;
       const size_t row = ((size_t)b * T + it) * 12;
       if (actual) for (int c = 0; c < 12; c++) actual[row + c] = x[b * NX + c];               /* src/mpc.py:295 */
@@ -742,7 +747,7 @@ int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* xv, voi
       for (int c = 0; c < 12; c++) x[b * NX + c] = X[(b * (N + 1) + 1) * NX + c];
       for (int a = 0; a < 3; a++) rf[3 + a] += gate * rf[6 + a] * d;                          /* src/mpc.py:261 */
       rf[2] += gate * rf[9] * d;                                                              /* src/mpc.py:262 */
-      tick[b] = t0 + 1;
+      tick[b] = tick[b] + 1;
     }
   }
   free(r); free(xd); free(u); free(X); free(ct); free(st);

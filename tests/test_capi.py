@@ -22,7 +22,7 @@ def test_product_library_exports_all_symbols():
     lib = mpcqp.product_library()            # fails loudly if the HIP library has not been built
     for sym in _declared_symbols():
         assert hasattr(lib.lib, sym), sym
-    assert lib.version() == 0x00010000
+    assert lib.version() == 0x00010100
 
 
 def test_oracle_exports_same_symbols(oracle_lib):
@@ -58,6 +58,14 @@ def test_host_layer_scales_the_admm_block_with_the_horizon(oracle_lib):
     flags = mpcqp.product_library().default_config(
         flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_WARM_START | mpcqp.FLAG_WARM_SHIFT | mpcqp.FLAG_NATURAL_ORDER).flags
     assert flags == 1 | 2 | 16 | 8
+
+
+def test_product_library_reads_no_environment():
+    """Solver behaviour is a function of MpcQpConfig alone: the product library does not import getenv (round-2 review: developer
+    knobs read from the environment could silently change a caller's results)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", mpcqp.product_library().path], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out
 
 
 def test_product_never_falls_back_to_cpu():

@@ -204,15 +204,13 @@ def test_edge_cases(oracle_solve):
     assert o["u"].shape == (0, 10, 12)
 
 
-def test_inverse_updates_give_the_rebuilds_answers(monkeypatch):
+def test_inverse_updates_give_the_rebuilds_answers():
     """Polish steps that follow another update -S^-1 (Sherman-Morrison on the changed leg-stages) instead of rebuilding it
-    (DESIGN.md section 3).  With the updates switched off (developer knob MPCQP_INCR_LEGS=0, read at mpcqp_create) every step
-    rebuilds: same statuses, same step counts, forces equal to rounding."""
+    (DESIGN.md section 3).  With the updates switched off (MpcQpConfig.incr_legs = -1) every step rebuilds: same statuses, same
+    step counts, forces equal to rounding."""
     for N, b in ((10, mpcqp.synth.config3(1024)), (20, mpcqp.synth.config5(512))):
         upd = gpu_solve(b, N=N, io="f64", precision="mixed")
-        monkeypatch.setenv("MPCQP_INCR_LEGS", "0")
-        reb = gpu_solve(b, N=N, io="f64", precision="mixed")
-        monkeypatch.delenv("MPCQP_INCR_LEGS")
+        reb = gpu_solve(b, N=N, io="f64", precision="mixed", incr_legs=-1)
         assert np.array_equal(upd["status"], reb["status"]) and np.array_equal(upd["iters"], reb["iters"])
         assert (upd["iters"] // 1000).max() >= 3                          # (some QPs do take several steps in a round)
         assert rel_err(upd["u"], reb["u"]).max() <= 1e-8, rel_err(upd["u"], reb["u"]).max()

@@ -58,16 +58,26 @@ def test_c_oracle_matches_numpy_restatement_and_kkt(oracle_solve, disc):
         x0, r, c, xd, mu = b["x0"][i], b["r"][i], b["contact"][i], b["xdes"][i], b["mu"][i]
         H, g, c0, G, lo, hi, *_ = S.condensed_qp(x0, r, c, xd, mu, cfg)
         u = ref["u"][i].reshape(-1)
-        # duals by least squares on the active rows, then the explicit KKT certificate
+        # multipliers by a SIGN-CONSTRAINED least-squares fit on the active rows (y >= 0 on rows at their upper bound, y <= 0 at
+        # their lower bound, free on equality rows), then the full KKT certificate: stationarity with multipliers of the right
+        # sign IS optimality of the convex QP -- an unconstrained fit would certify stationary points of the wrong active set too
+        from scipy.optimize import lsq_linear
         Gu = G @ u
-        act = (np.abs(Gu - lo) <= 1e-7 * np.maximum(1, np.abs(lo))) | (np.abs(Gu - hi) <= 1e-7 * np.maximum(1, np.abs(hi)))
+        at_lo = np.isfinite(lo) & (np.abs(Gu - np.where(np.isfinite(lo), lo, 0.0)) <= 1e-7 * np.maximum(1, np.abs(np.where(np.isfinite(lo), lo, 0.0))))
+        at_hi = np.isfinite(hi) & (np.abs(Gu - np.where(np.isfinite(hi), hi, 0.0)) <= 1e-7 * np.maximum(1, np.abs(np.where(np.isfinite(hi), hi, 0.0))))
+        act = at_lo | at_hi
         y = np.zeros(len(lo))
         if act.any():
-            y[act] = np.linalg.lstsq(G[act].T, -(H @ u + g), rcond=None)[0]
+            lb = np.where(at_lo[act], -np.inf, 0.0)
+            ub = np.where(at_hi[act], np.inf, 0.0)
+            fit = lsq_linear(G[act].T, -(H @ u + g), bounds=(lb, ub), method="bvls", tol=1e-14, max_iter=2000)
+            y[act] = fit.x
         k = S.kkt_report(H, g, G, lo, hi, u, y)
         scale = max(1.0, np.abs(g).max())
         assert k["stationarity"] <= 1e-7 * scale, k
         assert k["primal"] <= 1e-7 * max(1.0, np.abs(u).max()), k
+        assert k["dual_sign"] <= 1e-9 * scale, k
+        assert k["complementarity"] <= 1e-6 * scale, k               # |y| ~ scale times a bound gap <= 1e-7 |bound|
         # predicted states: literal recursion in numpy vs the C oracle's rollout
         assert np.abs(S.predict_states(x0, u, r, c, cfg) - ref["X"][i]).max() <= 1e-10
     # numpy solver path agrees with the C solver path
@@ -237,9 +247,11 @@ def test_logged_stage0_forces_obey_bounds_and_friction(golden):
     assert (np.abs(F[st][:, :2]).max(axis=1) - 0.5 * fz).max() > slack
 
 
-def _logged_prediction_vs_sparse_rows(golden, i, t, mutate=None):
+def _logged_prediction_vs_sparse_rows(golden, i, t, mutate=None, stage0_forces=False):
     """Residual of the logged prediction i (tick t) on every row of the literal sparse QP (src/mpc.py:113-173) whose
-    variables were all logged; returns {row class: max violation}, the OSQP termination bound, and J_log."""
+    variables were all logged; returns {row class: max violation}, the OSQP termination bound, and J_log.
+    ``stage0_forces``: also fill the 12 stage-0 forces of the same solve (the return value of MPC.solve that the caller logs,
+    src/main.py:216-218 -> FORCES[t]): the stage-0 rows of the omega / v_xy dynamics and of the friction pyramid become checkable."""
     L, q = golden["ref_log"], golden["qp_inputs"]
     N = 60
     cfg = S.QPConfig(N=N, delta=0.01, alpha=0.0)
@@ -252,6 +264,9 @@ def _logged_prediction_vs_sparse_rows(golden, i, t, mutate=None):
     z = np.full(nX + 12 * N, np.nan)
     z[:nX] = np.vstack([L[f"pred{i}_state"], np.full((1, N + 1), -9.81)]).T.reshape(-1)
     z[nX + 2::3] = L[f"pred{i}_fz"].T.reshape(-1)                     # f_z of leg l, stage k at 12 k + 3 l + 2
+    if stage0_forces:
+        assert np.array_equal(L["forces"][t].reshape(4, 3)[:, 2], L[f"pred{i}_fz"][:, 0])   # the same solve's output, logged twice
+        z[nX:nX + 12] = L["forces"][t]
     known = ~np.isnan(z)
     rows_ok = ~np.any((A != 0) & ~known[None, :], axis=1)
     Az = A @ np.where(known, z, 0.0)
@@ -270,7 +285,8 @@ def test_logged_predictions_meet_osqp_primal_bound_on_sparse_rows(golden, i, t):
     assert nrows >= 1500
     want = {"x0", "dyn_0", "dyn_1", "dyn_2", "dyn_3", "dyn_4", "dyn_5", "dyn_11", "dyn_12", "gpin", "swing", "fz_lo", "fz_hi"}
     assert want <= set(res)
-    assert not ({"dyn_6", "dyn_7", "dyn_8", "dyn_9", "dyn_10", "fric_x", "fric_y"} & set(res))   # need f_x / f_y: not logged
+    assert not ({"dyn_6", "dyn_7", "dyn_8", "dyn_9", "dyn_10", "fric_x", "fric_y"} & set(res))   # need f_x / f_y: the predictions' were
+                                                                                                 # not logged (stage 0: next test)
     assert 0.05 < bound < 0.1
     for name in want:
         assert res[name] <= bound, (name, res[name], bound)
@@ -338,6 +354,66 @@ def test_sign_or_scale_error_in_a_block_is_caught_by_the_log(golden, mutate, cls
         assert bad[cls] > bound and bad[cls] > 10 * base[cls], (cls, base[cls], bad[cls], bound)
     else:
         assert bad[cls] > 3 * base[cls], (cls, base[cls], bad[cls])
+
+
+# The log holds all 12 stage-0 forces of the two solves whose predictions it kept (FORCES[t], src/main.py:216-218): with them the
+# stage-0 rows of the omega dynamics (the Ihat^-1 [r]x block of B, src/mpc.py:98-107 -- the most error-prone block of the model),
+# of the v_x / v_y dynamics (1 / m) and of the friction pyramid (src/mpc.py:159-173) have a reference-held witness too.
+STAGE0_ROWS = ("dyn_6", "dyn_7", "dyn_8", "dyn_9", "dyn_10", "fric_x", "fric_y")
+
+
+@pytest.mark.parametrize("i,t", [(0, 0), (1, 80)])
+def test_logged_stage0_forces_meet_osqp_bound_on_omega_vxy_friction_rows(golden, i, t):
+    res, bound, nrows = _logged_prediction_vs_sparse_rows(golden, i, t, stage0_forces=True)
+    assert set(STAGE0_ROWS) <= set(res)
+    for name in STAGE0_ROWS:
+        assert res[name] <= bound, (name, res[name], bound)
+    # observed levels (regression pins): the omega rows hold to 2e-3, v_xy to 4e-3, the friction rows exactly
+    assert max(res[k] for k in ("dyn_6", "dyn_7", "dyn_8")) <= 2e-3, res
+    assert max(res[k] for k in ("dyn_9", "dyn_10")) <= 5e-3, res
+    assert res["fric_x"] <= 1e-3 and res["fric_y"] <= 1e-3, res
+
+
+def _mut_torque_sign(A, lo, hi, lab, c):           # tau = -(r x f): the Ihat^-1 [r]x block with the wrong sign (src/mpc.py:98-107)
+    for a in range(3):
+        rows = np.where(lab == "dyn_%d" % (6 + a))[0]
+        A[np.ix_(rows, np.arange(13 * 61, A.shape[1]))] *= -1
+    return A, lo, hi
+
+
+def _mut_mass_xy(A, lo, hi, lab, c):               # m = 8.885 / 2 in the v_x / v_y rows
+    for a in range(2):
+        rows = np.where(lab == "dyn_%d" % (9 + a))[0]
+        A[np.ix_(rows, np.arange(13 * 61, A.shape[1]))] *= 2
+    return A, lo, hi
+
+
+def _mut_friction_half(A, lo, hi, lab, c):         # mu = 0.5 instead of params['mu'] = 1 (src/main.py:40)
+    rows = np.where((lab == "fric_x") | (lab == "fric_y"))[0]
+    cols = 13 * 61 + 2 + 3 * np.arange(240)
+    A[np.ix_(rows, cols)] *= 0.5
+    return A, lo, hi
+
+
+def _mut_inertia_swapped(A, lo, hi, lab, c):       # I_body_inv = diag(1, 1/0.24, 1): pitch row scaled by 1/0.24 (src/mpc.py:73-76)
+    rows = np.where(lab == "dyn_7")[0]
+    A[np.ix_(rows, np.arange(13 * 61, A.shape[1]))] *= 1.0 / 0.24
+    return A, lo, hi
+
+
+@pytest.mark.parametrize("t_i", [(0, 0), (1, 80)])
+@pytest.mark.parametrize("mutate,cls,factor", [(_mut_torque_sign, "dyn_7", 10.0), (_mut_mass_xy, "dyn_9", 2.5),
+                                              (_mut_friction_half, "fric_x", None), (_mut_inertia_swapped, "dyn_7", 10.0)])
+def test_stage0_force_witness_catches_torque_mass_and_friction_errors(golden, t_i, mutate, cls, factor):
+    """The stage-0 witness discriminates: a flipped torque sign, a wrong pitch inertia, a halved mass in the v_xy rows or a halved
+    friction coefficient each raise the residual of their row class several-fold (the pitch row: 1.5e-3 -> 5.8e-2 at t = 0)."""
+    i, t = t_i
+    base, bound, _ = _logged_prediction_vs_sparse_rows(golden, i, t, stage0_forces=True)
+    bad, _, _ = _logged_prediction_vs_sparse_rows(golden, i, t, mutate, stage0_forces=True)
+    if factor is None:
+        assert bad[cls] > bound and base[cls] <= 1e-3, (cls, base[cls], bad[cls], bound)
+    else:
+        assert bad[cls] > factor * base[cls] and bad[cls] > 1e-2, (cls, base[cls], bad[cls])
 
 
 def test_logged_prediction_objective_gap(golden):
