@@ -78,6 +78,8 @@ extern "C" {
                                         QPs dearest-expected-first from a queue (a pre-pass ranks the support patterns by
                                         friction demand): same per-QP results, shorter launch */
 
+#define MPCQP_FLAG_STAGE_KERNEL 128u  /* product library: use the stage-wise (Riccati) engine (mpcqp_stage.h) at horizons 10 and 20 as well, where the
+                                        dense wrench-space engine is the default; other horizons (up to 64) always use it */
 #define MPCQP_FLAG_NO_TIMING 64u     /* product library: do not record the HIP event pair around each solve that mpcqp_last_kernel_ms()
                                         reads (two extra packets on the stream per call, ~15 us of a 0.46 ms solve of 4096 QPs);
                                         mpcqp_last_kernel_ms() then returns MPCQP_EINVAL */
@@ -88,7 +90,8 @@ extern "C" {
  */
 typedef struct MpcQpConfig {
   uint32_t size;        /* sizeof(MpcQpConfig) */
-  int32_t N;            /* horizon, params['N'] (src/mpc.py:30); engine supports 10 and 20 (all precisions at both) */
+  int32_t N;            /* horizon, params['N'] (src/mpc.py:30): 1..64.  10 and 20 run on the dense wrench-space engine, every other
+                           horizon -- the reference's committed 60 (src/main.py:37) -- on the stage-wise engine */
   double delta;         /* params['world_time_step'] (src/mpc.py:31) */
   double m;             /* 8.885 (src/mpc.py:71) */
   double Ibody_inv[3];  /* diag(1/0.24, 1, 1) (src/mpc.py:73-76) */
@@ -121,6 +124,9 @@ typedef struct MpcQpConfig {
                            0: 4; -1: always queued */
   float adapt_thr;      /* residual ratio at the early rho check beyond which a QP gets a larger penalty and a longer block; 0: per precision */
   double alpha_floor;   /* where the regulariser continuation of an alpha = 0 request ends; 0: 3e-6 */
+  int32_t polish_patience; /* polish steps of a round that may fail to halve the KKT violation before the round gives up; 0: default */
+  int32_t polish_cheap_steps; /* ... and the further steps a round may take beyond that as long as each only UPDATES S^-1 (few changed
+                                 leg-stages); 0: default, -1: none */
 } MpcQpConfig;
 
 typedef struct mpcqp_engine* mpcqp_handle;

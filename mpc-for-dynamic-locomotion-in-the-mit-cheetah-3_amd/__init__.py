@@ -7,7 +7,7 @@ mirror of the reference's ``MPC.solve`` surface and its planner glue, and the sy
 """
 from . import _capi, dist, engine, footstep_planner, synth  # noqa: F401
 from .engine import MPCBatch  # noqa: F401
-from ._capi import (DISC_EULER, DISC_ZOH, DTYPE_F32, DTYPE_F64, FLAG_NATURAL_ORDER, FLAG_POLISH, FLAG_TILE_KERNEL, FLAG_NO_TIMING, FLAG_WARM_SHIFT, FLAG_WARM_START, PREC_F32,  # noqa: F401
+from ._capi import (DISC_EULER, DISC_ZOH, DTYPE_F32, DTYPE_F64, FLAG_NATURAL_ORDER, FLAG_POLISH, FLAG_TILE_KERNEL, FLAG_NO_TIMING, FLAG_STAGE_KERNEL, FLAG_WARM_SHIFT, FLAG_WARM_START, PREC_F32,  # noqa: F401
                     PREC_F64, PREC_MIXED, Engine, Library, MpcQpConfig, MpcQpError, product_library)
 
 __all__ = ["Engine", "Library", "MPCBatch", "MpcQpConfig", "MpcQpError", "product_library", "synth"]

@@ -22,6 +22,7 @@ DISC_EULER, DISC_ZOH = 0, 1
 DTYPE_F32, DTYPE_F64 = 0, 1
 PREC_F32, PREC_MIXED, PREC_F64 = 0, 1, 2
 FLAG_POLISH, FLAG_WARM_START, FLAG_GENERAL_KERNEL, FLAG_NATURAL_ORDER, FLAG_WARM_SHIFT, FLAG_TILE_KERNEL, FLAG_NO_TIMING = 1, 2, 4, 8, 16, 32, 64
+FLAG_STAGE_KERNEL = 128
 
 EXPORTED_SYMBOLS = (
     "mpcqp_version", "mpcqp_default_config", "mpcqp_create", "mpcqp_destroy", "mpcqp_solve_batch",
@@ -39,6 +40,7 @@ class MpcQpConfig(ctypes.Structure):
         ("relax", c_double), ("max_iter", c_int32), ("check_every", c_int32),
         ("eps_abs", c_double), ("eps_rel", c_double), ("polish_max", c_int32), ("device", c_int32),
         ("first_block", c_int32), ("incr_legs", c_int32), ("listed_max", c_int32), ("adapt_thr", c_float), ("alpha_floor", c_double),
+        ("polish_patience", c_int32), ("polish_cheap_steps", c_int32),
     ]
 
     def as_dict(self):

@@ -46,6 +46,8 @@ struct DevCfg {
   int first_block;      // wrench engine: iterations of a cold solve's first ADMM block (0: check_every)
   int incr_legs;        // wrench engine: changed leg-stages up to which a polish step updates the inverse (0: always rebuild)
   float adapt_thr;      // wrench engine: residual ratio at the early rho check beyond which a QP gets a larger penalty and a longer block
+  int patience;         // wrench engine: polish steps of a round that may fail to halve the KKT violation before the round gives up
+  int cheap_steps;      // wrench engine: ... and the steps a round may go on beyond that while they only update the inverse
 };
 
 // Problem constants staged in LDS in the vector precision (keeps ~100 scalar registers free).

@@ -6,6 +6,7 @@
 // This translation unit is the C-ABI of include/mpcqp.h and the dispatch between three device implementations:
 //   mpcqp_wrench.h   the engine: wrench-space (Woodbury) form, H = 2 alpha I + T'KT with a 6N x 6N system, one QP per wave
 //                    (horizon 10) or per four waves (horizon 20), fp32 or fp64 ADMM, fp64 active-set polish, ADMM-only mode
+//   mpcqp_stage.h    stage-wise (Riccati) form of the same engine for any other horizon up to 64 -- the reference's own N = 60
 //   mpcqp_fast.h     round-1 horizon-10 kernel (120 x 120 closed-form register tiles over three waves): all-fp32 arithmetic,
 //                    weights the wrench form does not admit, MPCQP_FLAG_TILE_KERNEL
 //   mpcqp_general.h  round-1 single-launch state machine: alpha = 0 with polish requested, horizon 20 in fp32
@@ -16,6 +17,7 @@
 #include "mpcqp_general.h"
 #include "mpcqp_fast.h"
 #include "mpcqp_wrench.h"
+#include "mpcqp_stage.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -183,6 +185,9 @@ struct mpcqp_engine {
   void* gait_mem = nullptr;   // gait entry point: the expanded operator tuple [r | xdes | contact] of the current batch
   int64_t gait_cap = 0;
   bool wrench_ok = false;     // the configuration admits the wrench-space form (isotropic omega weight, positive velocity weights)
+  bool form_ok = false;       // ... the same condition without the horizon-specific tables (stage-wise engine)
+  double* stage_ws = nullptr; // stage-wise engine: factor workspace of the resident workgroups
+  int stage_slots = 0;        // ... and how many of them the device holds
   float* dual_mem = nullptr;  // warm-started engines: multipliers of the previous solve per batch slot [dual_cap][4 N][5]
   int64_t dual_cap = 0;
   bool timed = false;
@@ -192,6 +197,8 @@ struct mpcqp_engine {
 };
 
 namespace {
+
+bool stage_path_applies(const mpcqp_engine* h);
 
 int fail(mpcqp_engine* e, int code, const char* what, hipError_t he = hipSuccess) {
   if (e) {
@@ -282,11 +289,30 @@ hipError_t launch_wrench_n(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, vo
   return launch_wrench<TIO, 20>(e, B, in, u, X, st, it, res, s);
 }
 
+// Stage-wise engine (mpcqp_stage.h): persistent workgroups, one QP at a time each, with a factor workspace per workgroup.
+template <typename TIO>
+hipError_t launch_stage(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it, float* res, hipStream_t s) {
+  const int64_t slots = e->stage_slots > 0 ? e->stage_slots : 256;
+  const dim3 grid((unsigned)(B < slots ? B : slots));
+  if (e->cfg.precision == MPCQP_PREC_F64)
+    hipLaunchKernelGGL((mpcqp_stage_solve<double, TIO>), grid, dim3(SG_NT), 0, s, e->dcfg, in, (TIO*)u, (TIO*)X, st, it, res, e->stage_ws, e->cfg.N, (int)B);
+  else
+    hipLaunchKernelGGL((mpcqp_stage_solve<float, TIO>), grid, dim3(SG_NT), 0, s, e->dcfg, in, (TIO*)u, (TIO*)X, st, it, res, e->stage_ws, e->cfg.N, (int)B);
+  return hipGetLastError();
+}
+
 // Workspace that depends on the batch size: the dispatch-order buffer of the queued launch forms and, for warm-started
 // engines, the per-slot multiplier record.  Sized by mpcqp_reserve(); a solve at a larger B than reserved grows them on the
 // spot (a device-wide synchronisation + allocation -- the only ones a solve can make, and only the first time).
 int reserve_workspace(mpcqp_engine* e, int64_t B) {
   if (B <= 0) return MPCQP_OK;
+  if (stage_path_applies(e)) {   // (fixed size: one factor workspace per resident workgroup)
+    if (!e->stage_ws) {
+      const int64_t slots = e->stage_slots > 0 ? e->stage_slots : 256;
+      if (hipMalloc((void**)&e->stage_ws, (size_t)slots * SG_WS_DOUBLES * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); e->stage_ws = nullptr; return MPCQP_ENOMEM; }
+    }
+    return MPCQP_OK;
+  }
   if (e->order_cap < B) {
     int* mem = nullptr;
     const int64_t cap = ((B + 1023) / 1024) * 1024;
@@ -332,7 +358,13 @@ struct DeviceGuard {
   ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
+bool stage_path_applies(const mpcqp_engine* h) {
+  if (!h->form_ok || (h->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL))) return false;
+  return (h->cfg.N != 10 && h->cfg.N != 20) || (h->cfg.flags & MPCQP_FLAG_STAGE_KERNEL);
+}
+
 bool wrench_path_applies(const mpcqp_engine* h) {
+  if (h->cfg.flags & MPCQP_FLAG_STAGE_KERNEL) return false;
   // (any alpha >= 0: a request below 1e-2 -- the reference's own 0.0 included -- is served by continuation, mpcqp_wrench.h)
   return h->wrench_ok && h->cfg.precision != MPCQP_PREC_F32 && !(h->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL));
 }
@@ -421,6 +453,7 @@ static void free_engine(mpcqp_engine* h) {
   if (h->wr_K) (void)hipFree(h->wr_K);
   if (h->wr_kinv32) (void)hipFree(h->wr_kinv32);
   if (h->wr_kinv64) (void)hipFree(h->wr_kinv64);
+  if (h->stage_ws) (void)hipFree(h->stage_ws);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   delete h;
@@ -463,7 +496,7 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   e->cfg = *cfg;
   const int N = cfg->N;
   auto reject = [&](int code) { free_engine(e); return code; };
-  if (!(N == 10 || N == 20)) return reject(MPCQP_EINVAL);
+  if (N < 1 || N > SG_NS) return reject(MPCQP_EINVAL);
   if (cfg->precision < MPCQP_PREC_F32 || cfg->precision > MPCQP_PREC_F64) return reject(MPCQP_EINVAL);
   if (cfg->dtype != MPCQP_DTYPE_F32 && cfg->dtype != MPCQP_DTYPE_F64) return reject(MPCQP_EINVAL);
   if (cfg->disc != MPCQP_DISC_EULER && cfg->disc != MPCQP_DISC_ZOH) return reject(MPCQP_EINVAL);
@@ -505,6 +538,8 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   d.first_block = cfg->first_block > 0 ? cfg->first_block : (cfg->first_block < 0 ? 0 : ((cfg->flags & MPCQP_FLAG_POLISH) ? (7 * cfg->check_every) / 10 : 0));
   d.incr_legs = cfg->incr_legs > 0 ? (cfg->incr_legs < MPCQP_W_INCR_LEGS ? cfg->incr_legs : MPCQP_W_INCR_LEGS) : (cfg->incr_legs < 0 ? 0 : MPCQP_W_INCR_LEGS);
   e->listed_max = cfg->listed_max > 0 ? cfg->listed_max : (cfg->listed_max < 0 ? 0 : 4);
+  d.patience = cfg->polish_patience > 0 ? cfg->polish_patience : POLISH_PATIENCE;
+  d.cheap_steps = cfg->polish_cheap_steps > 0 ? cfg->polish_cheap_steps : (cfg->polish_cheap_steps < 0 ? 0 : POLISH_CHEAP_STEPS);
 
   // coefficient tables: c0[j][j'] = delta^2 (N - max(j,j')),
   // c1[j][j'] = delta^4 sum_{k > max(j,j')}^{N} (k-1-j+theta)(k-1-j'+theta)
@@ -521,14 +556,31 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
     }
   hipError_t he = hipMalloc((void**)&e->ctab, sizeof(double) * 2 * N * N);
   if (he == hipSuccess) he = hipMemcpy(e->ctab, tab, sizeof(double) * 2 * N * N, hipMemcpyHostToDevice);
-  if (he == hipSuccess) e->wrench_ok = N == 10 ? build_wrench_tables<10>(e, tab) : build_wrench_tables<20>(e, tab);
+  e->form_ok = cfg->w[6] == cfg->w[7];
+  for (int i = 6; i < 12; ++i) e->form_ok = e->form_ok && cfg->w[i] > 0;
+  if (he == hipSuccess && (N == 10 || N == 20)) e->wrench_ok = N == 10 ? build_wrench_tables<10>(e, tab) : build_wrench_tables<20>(e, tab);
+  // Other horizons (the reference's committed N = 60, src/main.py:37) and MPCQP_FLAG_STAGE_KERNEL: the stage-wise engine.
+  if (he == hipSuccess && (N != 10 && N != 20) && !e->form_ok) { delete[] tab; return reject(MPCQP_EINVAL); }
+  if (he == hipSuccess && stage_path_applies(e)) {
+    int per_cu = 0;
+    const bool f64 = e->cfg.precision == MPCQP_PREC_F64;
+    hipError_t oe;
+    if (cfg->dtype == MPCQP_DTYPE_F64)
+      oe = f64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mpcqp_stage_solve<double, double>, SG_NT, 0)
+               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mpcqp_stage_solve<float, double>, SG_NT, 0);
+    else
+      oe = f64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mpcqp_stage_solve<double, float>, SG_NT, 0)
+               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mpcqp_stage_solve<float, float>, SG_NT, 0);
+    if (oe != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+    e->stage_slots = per_cu * prop.multiProcessorCount;
+  }
   // All-fp32 arithmetic does not hold its 2e-2 band at horizon 20 (forces off by up to 9e-2 on 3 % of config 5, measured): such a
   // request is served with the MIXED arithmetic (fp32 tiles, fp64 residuals / polish) wherever the wrench-space engine applies.
-  if (he == hipSuccess && N != 10 && e->cfg.precision == MPCQP_PREC_F32 && e->wrench_ok &&
+  if (he == hipSuccess && N != 10 && e->cfg.precision == MPCQP_PREC_F32 && (e->wrench_ok || stage_path_applies(e)) &&
       !(e->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL)))
     e->cfg.precision = MPCQP_PREC_MIXED;
-  // (all-fp64 arithmetic at horizon 20 exists only in the wrench-space engine)
-  if (he == hipSuccess && cfg->precision == MPCQP_PREC_F64 && N != 10 && !wrench_path_applies(e)) { delete[] tab; return reject(MPCQP_EINVAL); }
+  // (all-fp64 arithmetic at horizon 20 exists only in the wrench-space and stage-wise engines)
+  if (he == hipSuccess && cfg->precision == MPCQP_PREC_F64 && N != 10 && !wrench_path_applies(e) && !stage_path_applies(e)) { delete[] tab; return reject(MPCQP_EINVAL); }
   delete[] tab;
   if (he == hipSuccess) he = hipMalloc((void**)&e->dcfg, sizeof(DevCfg));
   if (he == hipSuccess) he = hipMemcpy(e->dcfg, &e->dev, sizeof(DevCfg), hipMemcpyHostToDevice);
@@ -567,16 +619,28 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
   if (guard.err != hipSuccess) return fail(h, MPCQP_EHIP, "hipSetDevice", guard.err);
   hipStream_t st = (hipStream_t)stream;
   hipError_t he = hipSuccess;
-  const bool wrench = wrench_path_applies(h), fast = !wrench && fast_path_applies(h);
+  const bool stage = stage_path_applies(h);
+  const bool wrench = !stage && wrench_path_applies(h), fast = !stage && !wrench && fast_path_applies(h);
   const bool warm = (h->cfg.flags & MPCQP_FLAG_WARM_START) != 0;   // u_out is read as the initial guess first
-  if ((wrench || fast) && reserve_workspace(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_solve_batch: workspace allocation failed");
+  if ((stage || wrench || fast) && reserve_workspace(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_solve_batch: workspace allocation failed");
   float* ys = (warm && (fast || wrench) && B > 0) ? h->dual_mem : nullptr;
   const int shift = (h->cfg.flags & MPCQP_FLAG_WARM_SHIFT) ? 1 : 0;
   const bool timing = !(h->cfg.flags & MPCQP_FLAG_NO_TIMING) && !h->quiet;
   if (!h->ev0_set && timing) he = hipEventRecord(h->ev0, st);
   h->ev0_set = false;
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
-  if (B > 0 && (wrench || fast)) {
+  if (B > 0 && stage) {   // (cold solves: the stage-wise engine does not read the warm-start guess)
+    if (h->cfg.dtype == MPCQP_DTYPE_F64) {
+      const FastIn<double> in = {(const double*)x0, (const double*)r, contact, (const double*)xdes, (const double*)mu,
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+      he = launch_stage<double>(h, B, in, u_out, X_out, status, iters, res, st);
+    } else {
+      const FastIn<float> in = {(const float*)x0, (const float*)r, contact, (const float*)xdes, (const float*)mu,
+                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+      he = launch_stage<float>(h, B, in, u_out, X_out, status, iters, res, st);
+    }
+    if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
+  } else if (B > 0 && (wrench || fast)) {
     if (h->cfg.dtype == MPCQP_DTYPE_F64) {
       const FastIn<double> in = {(const double*)x0, (const double*)r, contact, (const double*)xdes, (const double*)mu,
                                  nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const double*)u_out : nullptr, ys, shift};

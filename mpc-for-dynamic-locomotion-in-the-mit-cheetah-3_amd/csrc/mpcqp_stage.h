@@ -1,0 +1,918 @@
+// mpcqp_stage.h -- stage-wise engine: any horizon up to 64 stages, the reference's committed N = 60 included (src/main.py:37,41).
+//
+// Same problem, same algorithm and same wrench-space form as mpcqp_wrench.h (OSQP ADMM to find the active set, primal-dual
+// active-set polish with a KKT acceptance test, regulariser continuation for small alpha; H = 2 alpha I + T'KT and every linear
+// system "diagonal + T'KT" reduced by Woodbury to  S y = b,  S = K^-1 + E,  E = T D^-1 T' block diagonal, 6 x 6 per stage) --
+// but S (6N x 6N: 360 x 360 at N = 60) is never formed.  K = C'(2W)C, where C maps a wrench sequence v to the deviation states
+// z_k = (P_k, Q_k) of six decoupled double integrators (the closed forms of DESIGN.md section 2, as a recursion):
+//     z_{k+1} = Phi z_k + Gam v_k,   Phi = [[I, d I], [0, I]],   Gam = [theta d^2 I ; d I],   z_0 = 0
+// so S y = b is the two-point boundary problem  v_k + E_k y_k = b_k,  y_k = Gam' lam_{k+1},  lam_k = Phi' lam_{k+1} + 2W z_k,
+// solved by a Riccati recursion (lam_k = Pi_k z_k + pi_k, Pi 12 x 12) -- O(N) per factorisation and per solve:
+//     Psi = Gam' Pi+ Gam,  Z = (Psi^-1 + E_k)^-1,  Ehat = Psi^-1 Z E_k  (= (I + E Psi)^-1 E, product form: E - E Z E cancels when
+//     the force weight is small),  L = Pi+ Gam Ehat,   Pi_k = 2W + Phi' (Pi+ - L (Pi+ Gam)') Phi
+//     backward  pi_k    = Phi' (I - L Gam') (Pi+ Gam b_k + pi_{k+1})
+//     forward   z_{k+1} = (I - Gam L') (Phi z_k + Gam (b_k - E_k Gam' pi_{k+1})),      y_k = Gam' (Pi_{k+1} z_{k+1} + pi_{k+1})
+// (numpy prototype against the dense system: tools/stage_proto.py, 1e-13 relative at alpha = 1e-2, 1e-9 at 1e-4).
+//
+// Mapping: one QP per workgroup of 256 lanes, ONE LANE PER LEG-STAGE (4 N <= 256): the leg's data and its ADMM / polish iterates
+// live in that lane's registers for the whole solve (no register tile exists here), stage sums are two DPP quad steps, and LDS
+// holds only the wrench-space vectors (6 N) and the recursion's states (12 N).  The two serial recursions of a solve run on ONE
+// group of 8 lanes -- lane c holds (P_c, Q_c) of wrench component c, the 6-vectors they need from each other are gathered with
+// DPP butterflies (lane ^ 1, ^ 2, ^ 3 by quad_perm, ^ 7 by row_half_mirror), no LDS on the critical path -- from per-stage factor
+// matrices that are stored in that butterfly order in a global-memory workspace (2.6 KB fp32 / 5.2 KB fp64 per stage: too large
+// for LDS at 64 stages) and prefetched one stage ahead; everything that does not depend on the recursion's carry (Pi+ Gam b_k,
+// E_k Gam' pi_{k+1}, y_k) is done by all lanes in parallel before / between / after the two chains.
+// The factorisation itself always runs in fp64 (wave 0, 6 x 6 inverses in LDS); the ADMM chains use its fp32 rounding in the
+// MIXED precision and fp64 in F64; the polish is all fp64.
+#pragma once
+#include "mpcqp_wrench.h"
+
+namespace {
+
+constexpr int SG_NS = 64;                 // stages a workgroup can hold
+constexpr int SG_NT = 256, SG_NW = 4;     // one lane per leg-stage
+constexpr int SG_NQ = 6 * SG_NS;
+// Workspace of one resident workgroup, in doubles: per stage  E (36, fp64) | Lrow (128 TM) | Lcol (128 TM) | PG (72 TM); the TM
+// parts are sized for fp64.
+constexpr int SG_WS_STAGE = 36 + 128 + 128 + 72;
+constexpr size_t SG_WS_DOUBLES = (size_t)SG_NS * SG_WS_STAGE;
+
+struct SmemS {
+  double x0[13];
+  double mu, cy, sy, rzw0[3], wP[6], wQ[6], delta, theta, alpha, inv_m, fmin, fmax, alpha_target, alpha_ok;
+  double gam[SG_NQ];                   // gradient of the cost in wrench space at u = 0
+  double ww[SG_NQ], kap[SG_NQ];        // wrench of the structured gradient's point, K ww + gam
+  double bq[SG_NQ], yq[SG_NQ];         // S y = b
+  double s0[SG_NS * 12];               // Pi+ Gam b_k (backward half), then d_k = b_k - E_k Gam' pi_{k+1} (forward half); setup: e0
+  double pist[(SG_NS + 1) * 12];       // pi_k, k = 1..N (index k); setup: x_des staging (with zst)
+  double zst[(SG_NS + 1) * 12];        // z_k, k = 0..N; structured gradient: the deviation states of its point
+  // factorisation scratch (wave 0)
+  double Pi[144], PG[72], Ps[36], Pinv[36], Zm[36], T1[36], Eh[36], Lm[72], Ek[36];
+  float red[SG_NW * 4];
+  float kkt[4], resid[4];
+  float gmax, rho, ratio;
+  int iters, psteps, hard, bad;
+  unsigned ahash, ahist[32];
+  uint8_t aset[SG_NT];
+  // The chains' factor matrices, staged in LDS (a chain step that waits for an L2 round trip costs ~0.6 us, measured): fp32 -- Lrow
+  // and Lcol of all stages, written here by the factorisation and resident for the whole ADMM block; fp64 -- the matrices of ONE
+  // direction, copied from the workspace by all lanes in front of each chain.
+  alignas(16) unsigned char fbuf[SG_NS * 128 * 8];
+};
+
+// One lane's leg-stage: model data and iterates (registers, for the whole solve).
+struct SLeg {
+  double B[9];                   // Rz Ihat^-1 [r]x masked by contact: B[3 i + a] (row i = angular component, column a = force axis)
+  double cm;                     // contact / m
+  double g[3];                   // linear term g = T' gam
+  double ua[3], za[5], ya[5];    // last ADMM iterate (multipliers unscaled)
+  double pu[3], py[5];           // polish iterate / last candidate
+  double uv[3];                  // point of the structured gradient; the accepted answer
+  bool stance, leg;
+};
+
+// g[s] = x of lane (lane ^ s) inside its group of 8.
+template <typename T>
+__device__ __forceinline__ void xor_gather8(const T x, T (&g)[8]) {
+  g[0] = x;
+  g[1] = dpp_mov<0xB1>(x);            // quad_perm [1,0,3,2]
+  g[2] = dpp_mov<0x4E>(x);            // quad_perm [2,3,0,1]
+  g[3] = dpp_mov<0x1B>(x);            // quad_perm [3,2,1,0]
+  const T x7 = dpp_mov<0x141>(x);     // row_half_mirror: lane i <-> 7 - i = i ^ 7
+  g[7] = x7;
+  g[6] = dpp_mov<0xB1>(x7);
+  g[5] = dpp_mov<0x4E>(x7);
+  g[4] = dpp_mov<0x1B>(x7);
+}
+
+// In-place inverse of a 6 x 6 SPD matrix in LDS by six symmetric sweeps (lanes 0..35 of wave 0, lane = 6 i + j); the wave's LDS
+// operations are in order, wsync<1> is a compiler fence.  M <- M^-1.
+__device__ __forceinline__ void sg_inv6(double* __restrict__ M, const int lane) {
+  const int i = lane / 6, j = lane - 6 * i;
+  const bool on = lane < 36;
+#pragma unroll 1
+  for (int p = 0; p < 6; ++p) {
+    double piv = 1.0, mip = 0.0, mpj = 0.0, mij = 0.0;
+    if (on) { piv = M[7 * p]; mip = M[6 * i + p]; mpj = M[6 * p + j]; mij = M[lane]; }
+    wsync<1>();
+    const double r = w_rcp(piv);
+    double v;
+    if (i == p && j == p) v = r;
+    else if (i == p) v = mpj * r;
+    else if (j == p) v = -mip * r;
+    else v = mij - mip * mpj * r;
+    if (on) M[lane] = v;
+    wsync<1>();
+  }
+}
+
+// C (6 x 6) = A (6 x 6) * B (6 x 6), all in LDS; lanes 0..35.  Ends with a fence.
+__device__ __forceinline__ void sg_mm6(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ Bm, const int lane) {
+  if (lane < 36) {
+    const int i = lane / 6, j = lane - 6 * i;
+    double a = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a = fma(A[6 * i + k], Bm[6 * k + j], a);
+    C[lane] = a;
+  }
+  wsync<1>();
+}
+
+// Riccati factorisation for the E_k blocks in the workspace (fp64), by wave 0; the other waves wait at the closing barrier.
+// Writes per stage, in TM: Lrow / Lcol (the rows / columns of L = Pi+ Gam Ehat in the butterfly order of the two chains) and
+// PG = Pi+ Gam.  kmin: stages below it keep the factors they have (unused: every call refactors all stages).
+template <typename TM>
+__device__ __forceinline__ void sg_factor(SmemS& s, double* __restrict__ ws, const int N, const int tid) {
+  if (tid < 64) {
+    const int lane = tid;
+    const double d = s.delta, th = s.theta, gp = th * d * d, gq = d;   // Gam = [gp I ; gq I]
+    for (int e = lane; e < 144; e += 64) { const int i = e / 12, j = e - 12 * i; s.Pi[e] = i == j ? 2.0 * (i < 6 ? s.wP[i] : s.wQ[i - 6]) : 0.0; }
+    wsync<1>();
+    double e_next = lane < 36 ? ws[(size_t)(N - 1) * SG_WS_STAGE + lane] : 0.0;
+#pragma unroll 1
+    for (int k = N - 1; k >= 0; --k) {
+      double* wk = ws + (size_t)k * SG_WS_STAGE;
+      TM* fac = reinterpret_cast<TM*>(wk + 36);
+      const double e_cur = e_next;
+      if (k > 0 && lane < 36) e_next = ws[(size_t)(k - 1) * SG_WS_STAGE + lane];
+      if (lane < 36) s.Ek[lane] = e_cur;
+      // PG = Pi Gam (12 x 6)
+      for (int e = lane; e < 72; e += 64) { const int i = e / 6, c = e - 6 * i; s.PG[e] = gp * s.Pi[12 * i + c] + gq * s.Pi[12 * i + 6 + c]; }
+      wsync<1>();
+      // Psi = Gam' PG (6 x 6, symmetric), inverted in place
+      if (lane < 36) { const int a = lane / 6, c = lane - 6 * a; const double v = gp * s.PG[6 * a + c] + gq * s.PG[6 * (6 + a) + c]; s.Ps[lane] = v; }
+      wsync<1>();
+      if (lane < 36) { const int a = lane / 6, c = lane - 6 * a; s.Pinv[lane] = 0.5 * (s.Ps[lane] + s.Ps[6 * c + a]); }
+      wsync<1>();
+      sg_inv6(s.Pinv, lane);
+      if (lane < 36) s.Zm[lane] = s.Pinv[lane] + s.Ek[lane];
+      wsync<1>();
+      sg_inv6(s.Zm, lane);
+      sg_mm6(s.T1, s.Zm, s.Ek, lane);           // Z E
+      sg_mm6(s.Ps, s.Pinv, s.T1, lane);         // Psi^-1 Z E (Ps reused)
+      if (lane < 36) { const int a = lane / 6, c = lane - 6 * a; s.Eh[lane] = 0.5 * (s.Ps[lane] + s.Ps[6 * c + a]); }
+      wsync<1>();
+      // L = PG Ehat (12 x 6)
+      for (int e = lane; e < 72; e += 64) {
+        const int i = e / 6, c = e - 6 * i;
+        double a = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) a = fma(s.PG[6 * i + q], s.Eh[6 * q + c], a);
+        s.Lm[e] = a;
+      }
+      wsync<1>();
+      // factors out (TM): butterfly layouts for the chains (group lane c, slot sl: partner j = c ^ sl), PG row-major
+      for (int e = lane; e < 128; e += 64) {
+        const int c = e >> 4, sl = e & 7, hi = (e >> 3) & 1, j = c ^ sl;
+        const bool okc = c < 6 && j < 6;
+        const TM lr = okc ? (TM)s.Lm[6 * (6 * hi + c) + j] : (TM)0;            // Lrow: rows P_c (hi = 0) / Q_c (hi = 1), column j
+        const TM lc = okc ? (TM)s.Lm[6 * (6 * hi + j) + c] : (TM)0;            // Lcol: column c, rows P_j / Q_j
+        if constexpr (sizeof(TM) == 4) {
+          reinterpret_cast<float*>(s.fbuf)[128 * k + e] = lr;
+          reinterpret_cast<float*>(s.fbuf)[SG_NS * 128 + 128 * k + e] = lc;
+        } else {
+          fac[e] = lr;
+          fac[128 + e] = lc;
+        }
+      }
+      for (int e = lane; e < 72; e += 64) fac[256 + e] = (TM)s.PG[e];
+      // Pi <- 2W + Phi' (Pi - L PG') Phi,  symmetrised.  M = Pi - L PG' first (each lane three entries, read before any write)
+      double m[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int e = lane + 64 * t;
+        m[t] = 0;
+        if (e < 144) {
+          const int i = e / 12, j = e - 12 * i;
+          double a = 0.5 * (s.Pi[e] + s.Pi[12 * j + i]);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) a -= 0.5 * (s.Lm[6 * i + q] * s.PG[6 * j + q] + s.Lm[6 * j + q] * s.PG[6 * i + q]);
+          m[t] = a;
+        }
+      }
+      wsync<1>();
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { const int e = lane + 64 * t; if (e < 144) s.Pi[e] = m[t]; }
+      wsync<1>();
+      // Phi' M Phi = [[Mpp, d Mpp + Mpq], [d Mpp + Mqp, d^2 Mpp + d (Mpq + Mqp) + Mqq]]
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int e = lane + 64 * t;
+        if (e < 144) {
+          const int i = e / 12, j = e - 12 * i, ib = i % 6, jb = j % 6;
+          const double Mpp = s.Pi[12 * ib + jb], Mpq = s.Pi[12 * ib + 6 + jb], Mqp = s.Pi[12 * (6 + ib) + jb], Mqq = s.Pi[12 * (6 + ib) + 6 + jb];
+          double v;
+          if (i < 6 && j < 6) v = Mpp;
+          else if (i < 6) v = d * Mpp + Mpq;
+          else if (j < 6) v = d * Mpp + Mqp;
+          else v = d * d * Mpp + d * (Mpq + Mqp) + Mqq;
+          if (i == j) v += 2.0 * (i < 6 ? s.wP[i] : s.wQ[i - 6]);
+          m[t] = v;
+        }
+      }
+      wsync<1>();
+#pragma unroll
+      for (int t = 0; t < 3; ++t) { const int e = lane + 64 * t; if (e < 144) s.Pi[e] = m[t]; }
+      wsync<1>();
+    }
+  }
+  __syncthreads();
+}
+
+// S y = b:  s.bq -> s.yq  with the factors in the workspace.  All lanes call.
+template <typename TM>
+__device__ __forceinline__ void sg_solve(SmemS& s, const double* __restrict__ ws, const int N, const int tid) {
+  const double d = s.delta, th = s.theta, gp = th * d * d, gq = d;
+  // (a) s0_k = PG_k b_k for k = 1..N-1 (stage 0 has no pi_0)
+  for (int e = tid; e < 12 * N; e += SG_NT) {
+    const int k = e / 12, i = e - 12 * k;
+    const TM* pg = reinterpret_cast<const TM*>(ws + (size_t)k * SG_WS_STAGE + 36) + 256 + 6 * i;
+    double a = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a = fma((double)pg[c], s.bq[6 * k + c], a);
+    s.s0[e] = a;
+  }
+  if (tid < 12) { s.pist[12 * N + tid] = 0.0; s.zst[tid] = 0.0; }
+  if constexpr (sizeof(TM) == 8) {   // Lrow of all stages -> LDS
+    double* fb = reinterpret_cast<double*>(s.fbuf);
+    for (int e = tid; e < 128 * N; e += SG_NT) fb[e] = ws[(size_t)(e >> 7) * SG_WS_STAGE + 36 + (e & 127)];
+  }
+  __syncthreads();
+  const TM* const frow = reinterpret_cast<const TM*>(s.fbuf);
+  const TM* const fcol = reinterpret_cast<const TM*>(s.fbuf) + (sizeof(TM) == 4 ? SG_NS * 128 : 0);
+  // (b) backward chain: group 0 of wave 0 (the other lanes of the wave run along on zeros)
+  if (tid < 64) {
+    const int c = tid & 7;
+    const bool on = tid < 6;
+    TM pp = 0, pq = 0;
+    TM Lr[16];
+    {
+      const TM* f = frow + 128 * (N - 1) + 16 * c;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) Lr[t] = f[t];
+    }
+#pragma unroll 1
+    for (int k = N - 1; k >= 1; --k) {
+      TM Ln[16];
+      {
+        const TM* f = frow + 128 * (k - 1) + 16 * c;   // (k - 1 = 0 is loaded and not used)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Ln[t] = f[t];
+      }
+      TM sp = on ? (TM)s.s0[12 * k + c] + pp : (TM)0, sq = on ? (TM)s.s0[12 * k + 6 + c] + pq : (TM)0;
+      const TM cc = (TM)gp * sp + (TM)gq * sq;
+      TM g[8];
+      xor_gather8(cc, g);
+      TM a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { a0 = fma(Lr[t], g[t], a0); a1 = fma(Lr[4 + t], g[4 + t], a1); b0 = fma(Lr[8 + t], g[t], b0); b1 = fma(Lr[12 + t], g[4 + t], b1); }
+      sp -= a0 + a1; sq -= b0 + b1;
+      pp = sp; pq = fma((TM)d, sp, sq);
+      if (on) { s.pist[12 * k + c] = (double)pp; s.pist[12 * k + 6 + c] = (double)pq; }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) Lr[t] = Ln[t];
+    }
+  }
+  __syncthreads();
+  // (c) d_k = b_k - E_k Gam' pi_{k+1}  (fp64 chains: Lcol of all stages -> LDS, the backward chain is done with Lrow)
+  if constexpr (sizeof(TM) == 8) {
+    double* fb = reinterpret_cast<double*>(s.fbuf);
+    for (int e = tid; e < 128 * N; e += SG_NT) fb[e] = ws[(size_t)(e >> 7) * SG_WS_STAGE + 36 + 128 + (e & 127)];
+  }
+  for (int e = tid; e < 6 * N; e += SG_NT) {
+    const int k = e / 6, c = e - 6 * k;
+    const double* Ek = ws + (size_t)k * SG_WS_STAGE + 6 * c;
+    const double* pk = s.pist + 12 * (k + 1);
+    double a = s.bq[e];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) a -= Ek[q] * (gp * pk[q] + gq * pk[6 + q]);
+    s.s0[12 * k + c] = a;
+  }
+  __syncthreads();
+  // (d) forward chain
+  if (tid < 64) {
+    const int c = tid & 7;
+    const bool on = tid < 6;
+    TM zp = 0, zq = 0;
+    TM Lc[16];
+    {
+      const TM* f = fcol + 16 * c;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) Lc[t] = f[t];
+    }
+#pragma unroll 1
+    for (int k = 0; k < N; ++k) {
+      TM Ln[16];
+      {
+        const TM* f = fcol + 128 * min(k + 1, N - 1) + 16 * c;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Ln[t] = f[t];
+      }
+      const TM dk = on ? (TM)s.s0[12 * k + c] : (TM)0;
+      const TM tp = zp + (TM)d * zq + (TM)gp * dk, tq = zq + (TM)gq * dk;
+      TM g0[8], g1[8];
+      xor_gather8(tp, g0);
+      xor_gather8(tq, g1);
+      TM a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { a0 = fma(Lc[t], g0[t], a0); a1 = fma(Lc[4 + t], g0[4 + t], a1); b0 = fma(Lc[8 + t], g1[t], b0); b1 = fma(Lc[12 + t], g1[4 + t], b1); }
+      const TM o = (a0 + a1) + (b0 + b1);
+      zp = tp - (TM)gp * o; zq = tq - (TM)gq * o;
+      if (on) { s.zst[12 * (k + 1) + c] = (double)zp; s.zst[12 * (k + 1) + 6 + c] = (double)zq; }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) Lc[t] = Ln[t];
+    }
+  }
+  __syncthreads();
+  // (e) y_k = PG_k' z_{k+1} + Gam' pi_{k+1}
+  for (int e = tid; e < 6 * N; e += SG_NT) {
+    const int k = e / 6, c = e - 6 * k;
+    const TM* pg = reinterpret_cast<const TM*>(ws + (size_t)k * SG_WS_STAGE + 36) + 256 + c;
+    const double* zk = s.zst + 12 * (k + 1);
+    const double* pk = s.pist + 12 * (k + 1);
+    double a = gp * pk[c] + gq * pk[6 + c];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a = fma((double)pg[6 * i], zk[i], a);
+    s.yq[e] = a;
+  }
+  __syncthreads();
+}
+
+// E_k = sum_legs A diag(dinv) A' (fp64) -> workspace.  Leg lanes (a quad = a stage).  Ends with a barrier.
+__device__ __forceinline__ void sg_build_E(const LegSys<double>& L, double* __restrict__ ws, const bool leg, const int tid) {
+  double e[21];
+  int k = 0;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+#pragma unroll
+    for (int p = q; p < 6; ++p) {
+      double a = L.dinv[0] * L.A[0][q] * L.A[0][p];
+      a = fma(L.dinv[1] * L.A[1][q], L.A[1][p], a);
+      a = fma(L.dinv[2] * L.A[2][q], L.A[2][p], a);
+      e[k++] = quad_sum(a);
+    }
+  }
+  if (leg && (tid & 3) == 0) {
+    double* Ej = ws + (size_t)(tid >> 2) * SG_WS_STAGE;
+    k = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+      for (int p = q; p < 6; ++p) { Ej[6 * q + p] = e[k]; Ej[6 * p + q] = e[k]; ++k; }
+    }
+  }
+  __syncthreads();
+}
+
+// x = M^-1 rhs,  M = D + A-stack' K A-stack:  x = dinv (rhs - A' S^-1 A-stack dinv rhs).  All lanes call.
+template <typename TM>
+__device__ __forceinline__ void sg_leg_solve(SmemS& s, const double* __restrict__ ws, const LegSys<double>& L, const double (&rhs)[3], double (&x)[3],
+                                             const bool leg, const int N, const int tid) {
+  double a[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a[c] = L.dinv[c] * rhs[c];
+  double b[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) b[q] = quad_sum(fma(L.A[2][q], a[2], fma(L.A[1][q], a[1], L.A[0][q] * a[0])));
+  if (leg && (tid & 3) == 0) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s.bq[6 * (tid >> 2) + q] = b[q];
+  }
+  __syncthreads();
+  sg_solve<TM>(s, ws, N, tid);
+  const double* yj = s.yq + 6 * (min(tid, 4 * N - 1) >> 2);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double sum = L.A[c][0] * yj[0];
+#pragma unroll
+    for (int q = 1; q < 6; ++q) sum = fma(L.A[c][q], yj[q], sum);
+    x[c] = a[c] - L.dinv[c] * sum;
+  }
+}
+
+// Adjoint recursion of the double integrators: out[6 j + q] = base[6 j + q] + Gam' lam_{j+1},  lam_k = Phi' lam_{k+1} + (muP_k, muQ_k)
+// with muP_k = 2 wP src[12 k + q], muQ_k = 2 wQ src[12 k + 6 + q], k = 1..N.  Six lanes (one per component).  No barrier inside.
+__device__ __forceinline__ void sg_adjoint(const SmemS& s, const double* __restrict__ src, const double* __restrict__ base, double* __restrict__ out,
+                                           const int N, const int tid) {
+  if (tid < 6) {
+    const int q = tid;
+    const double d = s.delta, gp = s.theta * d * d, w2p = 2.0 * s.wP[q], w2q = 2.0 * s.wQ[q];
+    double lP = 0, lQ = 0;
+#pragma unroll 4
+    for (int j = N - 1; j >= 0; --j) {
+      const double mP = w2p * src[12 * (j + 1) + q], mQ = w2q * src[12 * (j + 1) + 6 + q];
+      const double nP = lP + mP, nQ = fma(d, lP, lQ) + mQ;
+      lP = nP; lQ = nQ;
+      out[6 * j + q] = (base ? base[6 * j + q] : 0.0) + gp * lP + d * lQ;
+    }
+  }
+}
+
+// Structured gradient at the lane's force f: returns 2 alpha f + T'(K T f + gam) for the lane's leg; leaves the stage wrenches in
+// s.ww and the deviation states of f in s.zst.  All lanes call.
+__device__ __forceinline__ void sg_grad(SmemS& s, const SLeg& Lg, const double (&f)[3], double (&gr)[3], const int N, const int tid) {
+  {
+    double w6[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w6[i] = quad_sum(fma(Lg.B[3 * i + 2], f[2], fma(Lg.B[3 * i + 1], f[1], Lg.B[3 * i] * f[0])));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) w6[3 + a] = quad_sum(Lg.cm * f[a]);
+    if (Lg.leg && (tid & 3) == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) s.ww[6 * (tid >> 2) + q] = w6[q];
+    }
+  }
+  __syncthreads();
+  if (tid < 6) {   // deviation states of the wrench sequence, k = 1..N
+    const int q = tid;
+    const double d = s.delta, gp = s.theta * d * d;
+    double P = 0, Q = 0;
+#pragma unroll 4
+    for (int k = 0; k < N; ++k) {
+      const double w = s.ww[6 * k + q];
+      const double Pn = P + d * Q + gp * w, Qn = Q + d * w;
+      P = Pn; Q = Qn;
+      s.zst[12 * (k + 1) + q] = P; s.zst[12 * (k + 1) + 6 + q] = Q;
+    }
+  }
+  if (tid < 64) wsync<1>();
+  sg_adjoint(s, s.zst, s.gam, s.kap, N, tid);
+  __syncthreads();
+  {
+    const double* kj = s.kap + 6 * (min(tid, 4 * N - 1) >> 2);
+    const double a2 = 2.0 * s.alpha;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double g = fma(a2, f[a], Lg.cm * kj[3 + a]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) g = fma(Lg.B[3 * i + a], kj[i], g);
+      gr[a] = g;
+    }
+  }
+  __syncthreads();
+}
+
+// The leg's 6 x 3 wrench map and inverse diagonal: ADMM (D = 2 alpha + sigma + rho G'G) / polish (reduced variables, D = 2 alpha Z'Z).
+__device__ __forceinline__ void sg_admm_sys(const SmemS& s, const DevCfg& cfg, const SLeg& Lg, const double rho, LegSys<double>& Ls) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Ls.A[c][i] = Lg.B[3 * i + c];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) Ls.A[c][3 + a] = a == c ? Lg.cm : 0.0;
+  }
+  const double a2 = 2.0 * s.alpha, m = s.mu;
+  Ls.dinv[0] = Ls.dinv[1] = Lg.stance ? 1.0 / (a2 + cfg.sigma + 2.0 * rho) : 0.0;
+  Ls.dinv[2] = Lg.stance ? 1.0 / (a2 + cfg.sigma + rho * (1.0 + 4.0 * m * m)) : 0.0;
+}
+
+__device__ __forceinline__ void sg_polish_sys(const SmemS& s, const SLeg& Lg, const ActSet& a, LegSys<double>& Ls) {
+  const double muv = s.mu, txs = (double)a.xs * muv, tys = (double)a.ys * muv, cm = Lg.cm;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Ls.A[0][i] = a.ex ? Lg.B[3 * i] : 0.0;
+    Ls.A[1][i] = a.ey ? Lg.B[3 * i + 1] : 0.0;
+    Ls.A[2][i] = a.ez ? Lg.B[3 * i + 2] + txs * Lg.B[3 * i] + tys * Lg.B[3 * i + 1] : 0.0;
+  }
+  Ls.A[0][3] = a.ex ? cm : 0.0; Ls.A[0][4] = 0; Ls.A[0][5] = 0;
+  Ls.A[1][3] = 0; Ls.A[1][4] = a.ey ? cm : 0.0; Ls.A[1][5] = 0;
+  Ls.A[2][3] = a.ez ? txs * cm : 0.0; Ls.A[2][4] = a.ez ? tys * cm : 0.0; Ls.A[2][5] = a.ez ? cm : 0.0;
+  const double a2 = 2.0 * s.alpha;
+  Ls.dinv[0] = a.ex ? 1.0 / a2 : 0.0;
+  Ls.dinv[1] = a.ey ? 1.0 / a2 : 0.0;
+  Ls.dinv[2] = a.ez ? 1.0 / (a2 * (1.0 + muv * muv * (double)((a.xs != 0) + (a.ys != 0)))) : 0.0;
+}
+
+// The active-set rule of the polish on the lane's (pu, py) -> ActSet code (as w_polish_rule).
+__device__ __forceinline__ int sg_polish_rule(const SmemS& s, const SLeg& Lg) {
+  const double muv = s.mu, fminv = s.fmin, fmaxv = s.fmax;
+  int zs = 0, xs = 0, ys = 0;
+  if (Lg.stance) {
+    const double u0 = Lg.pu[0], u1 = Lg.pu[1], u2 = Lg.pu[2];
+    const double g1 = u0 - muv * u2, g2 = u0 + muv * u2, g3_ = u1 - muv * u2, g4 = u1 + muv * u2;
+    if (Lg.py[0] + (u2 - fmaxv) > 0) zs = 1;
+    else if (Lg.py[0] + (u2 - fminv) < 0) zs = -1;
+    const bool hx = Lg.py[1] + g1 > 0, lx = Lg.py[2] + g2 < 0;
+    if (hx && lx) xs = (g1 > -g2) ? 1 : -1; else if (hx) xs = 1; else if (lx) xs = -1;
+    const bool hy = Lg.py[3] + g3_ > 0, ly = Lg.py[4] + g4 < 0;
+    if (hy && ly) ys = (g3_ > -g4) ? 1 : -1; else if (hy) ys = 1; else if (ly) ys = -1;
+  }
+  return (zs + 1) | ((xs + 1) << 2) | ((ys + 1) << 4);
+}
+
+// OSQP's residuals and rho-adaptation ratio of the ADMM iterate (u, z, y) held by the leg lanes.  Uniform result; s.resid set.
+__device__ __forceinline__ float sg_ratio(SmemS& s, const SLeg& Lg, const double (&u)[3], const double (&z)[5], const double (&y)[5], const int N,
+                                          const int tid) {
+  double hv[3];
+  sg_grad(s, Lg, u, hv, N, tid);
+  float q[4] = {0.f, 0.f, 0.f, 0.f};
+  if (Lg.leg) {
+    const double mu = s.mu, m = mu * u[2];
+    const double gu[5] = {u[2], u[0] - m, u[0] + m, u[1] - m, u[1] + m};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      q[0] = fmaxf(q[0], fabsf((float)(gu[i] - z[i])));
+      q[2] = fmaxf(q[2], fmaxf(fabsf((float)gu[i]), fabsf((float)z[i])));
+    }
+    const double Gy[3] = {y[1] + y[2], y[3] + y[4], y[0] + mu * (-y[1] + y[2] - y[3] + y[4])};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      q[1] = fmaxf(q[1], fabsf((float)(hv[a] + Gy[a])));
+      q[3] = fmaxf(q[3], fmaxf(fabsf((float)(hv[a] - Lg.g[a])), fabsf((float)Gy[a])));
+    }
+  }
+  block_max<4, SG_NW>(q, s.red, tid);
+  const float sp = q[2], sd = fmaxf(q[3], s.gmax);
+  if (tid == 0) { s.resid[0] = q[0]; s.resid[1] = q[1]; s.resid[2] = sp; s.resid[3] = sd; }
+  __syncthreads();
+  return sqrtf((q[0] / fmaxf(sp, 1e-12f)) / fmaxf(q[1] / fmaxf(sd, 1e-12f), 1e-30f));
+}
+
+// One ADMM block (OSQP algorithm 1, scaled duals) from the lane's (ua, za, ya) with penalty s.rho; `adapt`: the single early rho
+// check of a cold solve's first block.  Updates s.rho / s.iters / s.hard and the lane's iterate (ua, za, ya) and polish start (pu, py).
+template <typename TM>
+__device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, double* __restrict__ ws, const int adapt, const int kfirst,
+                                        const int N, const int tid) {
+  float rho = s.rho;
+  int K = kfirst > 0 ? min(kfirst, cfg.check_every) : cfg.check_every;
+  K = max(1, min(K, cfg.max_iter - s.iters));
+  int it = 0, seg_end = (adapt && MPCQP_W_ADAPT_AT < K) ? MPCQP_W_ADAPT_AT : K;
+  int hard = 0;
+  float ratio = 0.f;
+  __syncthreads();   // (everyone has read s.rho / s.iters)
+  for (;;) {
+    LegSys<double> Ls;
+    sg_admm_sys(s, cfg, Lg, (double)rho, Ls);
+    sg_build_E(Ls, ws, Lg.leg, tid);
+    sg_factor<TM>(s, ws, N, tid);
+    const double sigma = cfg.sigma, relax = cfg.relax, om = 1.0 - relax, BIG = 1e30, r = (double)rho, mu = s.mu;
+    double u[3], z[5], yh[5];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) u[a] = Lg.ua[a];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { z[i] = Lg.za[i]; yh[i] = Lg.ya[i] / r; }
+    const double lo0 = Lg.stance ? s.fmin : 0.0, hi0 = Lg.stance ? s.fmax : 0.0, loA = Lg.stance ? -BIG : 0.0, hiB = Lg.stance ? BIG : 0.0;
+    bool rebuild = false;
+    for (;;) {
+      for (; it < seg_end; ++it) {
+        double v[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = z[k] - yh[k];
+        const double w0 = v[1] + v[2], w1 = v[3] + v[4], w2 = fma(mu, (v[2] - v[1]) + (v[4] - v[3]), v[0]);
+        const double rhs[3] = {fma(r, w0, fma(sigma, u[0], -Lg.g[0])), fma(r, w1, fma(sigma, u[1], -Lg.g[1])), fma(r, w2, fma(sigma, u[2], -Lg.g[2]))};
+        double ut[3];
+        sg_leg_solve<TM>(s, ws, Ls, rhs, ut, Lg.leg, N, tid);
+        const double mz = mu * ut[2];
+        const double gt[5] = {ut[2], ut[0] - mz, ut[0] + mz, ut[1] - mz, ut[1] + mz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) u[a] = fma(relax, ut[a], om * u[a]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const double lo = k == 0 ? lo0 : ((k & 1) ? loA : 0.0), hi = k == 0 ? hi0 : ((k & 1) ? 0.0 : hiB);
+          const double t = fma(relax, gt[k], om * z[k]) + yh[k];
+          const double zn = fmin(fmax(t, lo), hi);
+          yh[k] = t - zn;
+          z[k] = zn;
+        }
+      }
+      if (it >= K) break;
+      {
+        double y5[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) y5[k] = r * yh[k];
+        ratio = sg_ratio(s, Lg, u, z, y5, N, tid);
+      }
+      if (ratio > cfg.adapt_thr) { rebuild = true; break; }   // uniform
+      seg_end = K;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { Lg.ua[a] = u[a]; Lg.pu[a] = u[a]; }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const double y = r * yh[k]; Lg.za[k] = z[k]; Lg.ya[k] = y; Lg.py[k] = y; }
+    if (!rebuild) break;
+    rho = fminf(rho * ratio, ADAPT_RHO_MAX);
+    hard = 1;
+    K = max(K, min(HARD_ITER_FACTOR * K, cfg.max_iter - s.iters));
+    seg_end = K;
+  }
+  __syncthreads();
+  if (tid == 0) { s.rho = rho; s.iters += K; s.hard |= hard; }
+  __syncthreads();
+}
+
+// The polish steps of one round (as w_polish_round; every step refactors -- there is no dense inverse to update).  Returns 1 when a
+// step was accepted (answer in the lanes' uv), else 0 with (pu, py) the last candidate.
+__device__ __forceinline__ int sg_polish_round(SmemS& s, const DevCfg& cfg, SLeg& Lg, double* __restrict__ ws, const int budget, const bool last,
+                                               const int N, const int tid) {
+  int ok = 0, ps = 0, nstall = 0;
+  float vprev = INFINITY, vprev2 = INFINITY;
+  for (;;) {
+    const int code = sg_polish_rule(s, Lg);
+    if (Lg.leg) s.aset[tid] = (uint8_t)code;
+    if (tid == 0) s.ahash = 0u;
+    __syncthreads();
+    if (Lg.leg) atomicAdd(&s.ahash, ((unsigned)code + 1u) * (2654435761u * (unsigned)(2 * tid + 1)));
+    __syncthreads();
+    {   // an active set this round has already tried: the iteration would repeat itself
+      const unsigned h = s.ahash;
+      bool seen = false;
+      for (int k = 0; k < min(ps, 32); ++k) seen = seen || s.ahist[k] == h;
+      __syncthreads();
+      if (tid == 0 && ps < 32) s.ahist[ps] = h;
+      if (seen) break;   // uniform
+    }
+    const ActSet as(code, Lg.stance);
+    LegSys<double> Ls;
+    sg_polish_sys(s, Lg, as, Ls);
+    sg_build_E(Ls, ws, Lg.leg, tid);
+    sg_factor<double>(s, ws, N, tid);
+    const int zs = as.zs, xs = as.xs, ys = as.ys;
+    const bool ez = as.ez, ex = as.ex, ey = as.ey;
+    const double muv = s.mu, txs = (double)xs * muv, tys = (double)ys * muv;
+    double v3[3];
+    {
+      const double F = zs > 0 ? s.fmax : s.fmin;
+      v3[0] = ex ? Lg.pu[0] : 0.0; v3[1] = ey ? Lg.pu[1] : 0.0;
+      v3[2] = ez ? Lg.pu[2] : ((Lg.stance && zs != 0) ? F : 0.0);
+    }
+    double uc[3], gr3[3] = {0, 0, 0};
+    float stat = INFINITY, prev = INFINITY;
+    for (int rf = 0;; ++rf) {
+      uc[2] = v3[2]; uc[0] = ex ? v3[0] : txs * v3[2]; uc[1] = ey ? v3[1] : tys * v3[2];
+      sg_grad(s, Lg, uc, gr3, N, tid);
+      const double rg[3] = {ex ? gr3[0] : 0.0, ey ? gr3[1] : 0.0, ez ? gr3[2] + txs * gr3[0] + tys * gr3[1] : 0.0};
+      float q[2] = {Lg.leg ? fmaxf(fmaxf(fabsf((float)rg[0]), fabsf((float)rg[1])), fabsf((float)rg[2])) : 0.f,
+                    Lg.leg ? fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2])) : 0.f};
+      if (!isfinite(q[0])) q[0] = INFINITY;
+      block_max<2, SG_NW>(q, s.red, tid);
+      prev = stat; stat = q[0];
+      const float gmaxl = s.gmax;
+      const float tol_stat = 1e-6f + 1e-9f * gmaxl;
+      const float tol = fminf(tol_stat, 0.25f * 2.f * (float)s.alpha * 2e-5f * fmaxf(1.f, q[1]));
+      if (stat <= tol || rf >= 4 || (rf > 0 && !(stat < 0.5f * prev))) break;   // uniform
+      const double rhs[3] = {-rg[0], -rg[1], -rg[2]};
+      double dx[3];
+      sg_leg_solve<double>(s, ws, Ls, rhs, dx, Lg.leg, N, tid);
+      v3[0] += ex ? dx[0] : 0.0; v3[1] += ey ? dx[1] : 0.0; v3[2] += ez ? dx[2] : 0.0;
+    }
+    // duals from stationarity, primal feasibility + dual sign (thresholds: the fp64-buffer set of mpcqp_wrench.h)
+    const double fminv = s.fmin, fmaxv = s.fmax;
+    const float gmaxf = s.gmax;
+    const float acc_stat = 1e-5f + 1e-8f * gmaxf, ftol = 1e-7f, dtol = 1e-5f + 1e-9f * gmaxf;
+    double yn[5] = {0, 0, 0, 0, 0};
+    float viol[3] = {0.f, 0.f, 0.f};
+    if (Lg.leg && Lg.stance) {
+      double zacc = gr3[2];
+      if (xs > 0) { yn[1] = -gr3[0]; zacc += muv * (-yn[1]); }
+      else if (xs < 0) { yn[2] = -gr3[0]; zacc += muv * yn[2]; }
+      if (ys > 0) { yn[3] = -gr3[1]; zacc += muv * (-yn[3]); }
+      else if (ys < 0) { yn[4] = -gr3[1]; zacc += muv * yn[4]; }
+      if (zs != 0) yn[0] = -zacc;
+      const double g0 = uc[2], g1 = uc[0] - muv * uc[2], g2 = uc[0] + muv * uc[2], g3_ = uc[1] - muv * uc[2], g4 = uc[1] + muv * uc[2];
+      double pv = fmax(fminv - g0, g0 - fmaxv);
+      pv = fmax(pv, fmax(g1, -g2));
+      pv = fmax(pv, fmax(g3_, -g4));
+      double dv = fmax(fmax(-yn[1], yn[2]), fmax(-yn[3], yn[4]));
+      if (zs > 0) dv = fmax(dv, -yn[0]);
+      if (zs < 0) dv = fmax(dv, yn[0]);
+      viol[0] = (float)fmax(pv, 0.0);
+      viol[1] = (float)fmax(dv, 0.0);
+      viol[2] = fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2]));
+      if (!(isfinite(viol[0]) && isfinite(viol[1]))) viol[0] = viol[1] = INFINITY;
+    }
+    block_max<3, SG_NW>(viol, s.red, tid);
+    const float a2f = 2.f * (float)s.alpha, uscale = fmaxf(1.f, viol[2]);
+    const bool step_ok = viol[0] <= ftol * uscale && viol[1] <= fminf(dtol, a2f * 1e-5f * uscale) && stat <= fminf(acc_stat, a2f * 2e-5f * uscale);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { Lg.pu[c] = uc[c]; Lg.uv[c] = uc[c]; }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) Lg.py[i] = yn[i];
+    if (tid == 0) { s.kkt[0] = stat; s.kkt[1] = viol[0]; s.kkt[2] = viol[1]; s.psteps += 1; }
+    ok = step_ok ? 1 : 0;
+    const float v = viol[0] + viol[1] / fmaxf(s.gmax, 1.f) * 100.f;
+    ++ps;
+    __syncthreads();
+    if (ok || ps >= budget) break;
+    {
+      const int psd = ps - 1;
+      const bool one_sided = fminf(viol[0], viol[1]) <= 1e-9f;
+      const bool stalled = !(v < 0.5f * vprev);
+      const bool alternating = one_sided && psd >= 2 && psd < 4 && v < 0.5f * vprev2;
+      if (psd >= 1 && stalled && !alternating) ++nstall;
+      if (nstall >= cfg.patience && !last) break;   // uniform
+    }
+    vprev2 = vprev; vprev = v;
+  }
+  return ok;
+}
+
+// ----------------------------------------------------------------------------------------------------- the kernel
+// Persistent workgroups: workgroup w solves QPs w, w + gridDim.x, ...; its factor workspace is ws_all + w * SG_WS_DOUBLES.
+template <typename TM, typename TIO>
+__global__ void __launch_bounds__(SG_NT)
+mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug, TIO* __restrict__ Xg, int* __restrict__ statusg,
+                  int* __restrict__ itersg, float* __restrict__ resg, double* __restrict__ ws_all, const int N, const int Btot) {
+  __shared__ SmemS s;
+  const DevCfg& cfg = *cfgp;
+  const int tid = threadIdx.x, NL = 4 * N, NQ = 6 * N, n = 12 * N, NX = (N + 1) * 13;
+  double* const ws = ws_all + (size_t)blockIdx.x * SG_WS_DOUBLES;
+  for (int b = blockIdx.x; b < Btot; b += gridDim.x) {
+    SLeg Lg;
+    Lg.leg = tid < NL;
+    // ---- constants and inputs (src/mpc.py:242-255)
+    if (tid < 6) { s.wP[tid] = cfg.w[tid]; s.wQ[tid] = cfg.w[6 + tid]; }
+    if (tid == 0) {
+      s.delta = cfg.delta; s.theta = cfg.theta; s.inv_m = cfg.inv_m; s.fmin = cfg.fmin; s.fmax = cfg.fmax;
+      s.alpha_target = cfg.alpha > 0.0 ? cfg.alpha : ((cfg.flags & MPCQP_FLAG_POLISH) ? cfg.alpha_floor : 0.0);
+      s.alpha = ((cfg.flags & MPCQP_FLAG_POLISH) && cfg.alpha < ALPHA_EASY) ? ALPHA_EASY : cfg.alpha;
+      s.rho = (float)cfg.rho; s.iters = 0; s.psteps = 0; s.hard = 0;
+      s.kkt[0] = s.kkt[1] = s.kkt[2] = 0.f;
+    }
+    int bad = 0;
+    double* const xd = s.pist;   // x_des staging [N+1][13] over pist | zst (contiguous members)
+    static_assert(offsetof(SmemS, zst) == offsetof(SmemS, pist) + sizeof(double) * (SG_NS + 1) * 12, "x_des staging spans pist | zst");
+    for (int i = tid; i < NX; i += SG_NT) { const double v = (double)in.xdes[(size_t)b * NX + i]; xd[i] = v; bad |= !isfinite(v); }
+    if (tid < 13) { const double v = (double)in.x0[(size_t)b * 13 + tid]; s.x0[tid] = v; bad |= !isfinite(v); }
+    if (tid == 0) { const double v = (double)in.mu[b]; s.mu = v; bad |= !isfinite(v); }
+    double rr[3] = {0, 0, 0};
+    Lg.stance = false;
+    if (Lg.leg) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { rr[a] = (double)in.r[(size_t)b * n + 3 * tid + a]; bad |= !isfinite(rr[a]); }
+      Lg.stance = in.contact[(size_t)b * NL + tid] != 0;
+    }
+    bad = __syncthreads_or(bad);
+    if (bad) {   // non-finite input -> zero outputs, status -1
+      for (int i = tid; i < n; i += SG_NT) ug[(size_t)b * n + i] = (TIO)0;
+      if (Xg) for (int i = tid; i < NX; i += SG_NT) Xg[(size_t)b * NX + i] = (TIO)0;
+      if (tid == 0) { statusg[b] = MPCQP_STATUS_NONFINITE; itersg[b] = 0; if (resg) { resg[2 * b] = 0.f; resg[2 * b + 1] = 0.f; } }
+      __syncthreads();
+      continue;
+    }
+    if (tid == 0) {
+      const double yaw = s.x0[2];  // src/mpc.py:64
+      const double c = cos(yaw), sn = sin(yaw);
+      s.cy = c; s.sy = sn;
+      s.rzw0[0] = c * s.x0[6] - sn * s.x0[7];
+      s.rzw0[1] = sn * s.x0[6] + c * s.x0[7];
+      s.rzw0[2] = s.x0[8];
+    }
+    __syncthreads();
+    {   // src/mpc.py:71-78, 98-107; compute_skew column a = r x e_a (src/utils.py:43-56)
+      const double c = s.cy, sn = s.sy, Ib0 = cfg.Ib[0], Ib1 = cfg.Ib[1], Ib2 = cfg.Ib[2], m = Lg.stance ? 1.0 : 0.0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        double cx, cyv, cz;
+        if (a == 0) { cx = 0; cyv = rr[2]; cz = -rr[1]; }
+        else if (a == 1) { cx = -rr[2]; cyv = 0; cz = rr[0]; }
+        else { cx = rr[1]; cyv = -rr[0]; cz = 0; }
+        const double bx = (c * cx + sn * cyv) * Ib0, by = (-sn * cx + c * cyv) * Ib1, bz = cz * Ib2;
+        const double tx = c * bx - sn * by, ty = sn * bx + c * by;
+        Lg.B[a] = m * (c * tx - sn * ty);
+        Lg.B[3 + a] = m * (sn * tx + c * ty);
+        Lg.B[6 + a] = m * bz;
+      }
+      Lg.cm = Lg.stance ? s.inv_m : 0.0;
+    }
+    // free response minus target, stages k = 1..N, at s0[12 k + q] (P) / s0[12 k + 6 + q] (Q) -- index k - 1 is used so that it fits
+    for (int e = tid; e < NQ; e += SG_NT) {
+      const int j = e / 6, q = e - 6 * j, k = j + 1;
+      const double d = s.delta, th = s.theta, g = s.x0[12], kd = (double)k * d;
+      const double* xk = xd + 13 * k;
+      double eP, eQ;
+      if (q < 3) {
+        eP = s.x0[q] + kd * s.rzw0[q] - xk[q];
+        const double wx = xk[6], wy = xk[7], wz = xk[8];
+        const double rd = q == 0 ? s.cy * wx - s.sy * wy : (q == 1 ? s.sy * wx + s.cy * wy : wz);
+        eQ = s.rzw0[q] - rd;
+      } else {
+        const int a = q - 3;
+        eP = s.x0[3 + a] + kd * s.x0[9 + a] - xk[3 + a];
+        eQ = s.x0[9 + a] - xk[9 + a];
+        if (a == 2) { eP += d * d * g * ((double)(k * (k - 1)) * 0.5 + th * (double)k); eQ += kd * g; }
+      }
+      s.s0[12 * j + q] = eP; s.s0[12 * j + 6 + q] = eQ;
+    }
+    __syncthreads();
+    sg_adjoint(s, s.s0 - 12, nullptr, s.gam, N, tid);   // gam = C' 2W e  (src index k = j + 1 -> s0[12 j ..])
+    __syncthreads();
+    float q0[1] = {0.f};
+    {
+      const double* gj = s.gam + 6 * (min(tid, NL - 1) >> 2);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        double g = Lg.cm * gj[3 + a];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g = fma(Lg.B[3 * i + a], gj[i], g);
+        Lg.g[a] = g;
+        if (Lg.leg) q0[0] = fmaxf(q0[0], fabsf((float)g));
+      }
+    }
+    block_max<1, SG_NW>(q0, s.red, tid);
+    if (tid == 0) s.gmax = q0[0];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { Lg.ua[a] = 0; Lg.pu[a] = 0; Lg.uv[a] = 0; }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { Lg.za[i] = 0; Lg.ya[i] = 0; Lg.py[i] = 0; }
+    __syncthreads();
+    // ---- rounds: ADMM block, polish steps; on failure OSQP's rho adaptation and another round (mpcqp_wrench.h, same policy)
+    const int max_iter = cfg.max_iter, polish_max = cfg.polish_max;
+    const bool admm_only = !(cfg.flags & MPCQP_FLAG_POLISH);
+    int ok = 0;
+    enum { R_ADMM, R_CONT };
+    int kind = R_ADMM, round = 0, cont_retry = 0;
+    double keep_u[3] = {0, 0, 0}, keep_y[5] = {0, 0, 0, 0, 0};   // the last accepted continuation level
+    for (;;) {
+      int budget = 2 * polish_max;
+      if (kind == R_ADMM) {
+        sg_admm<TM>(s, cfg, Lg, ws, round == 0 ? 1 : 0, round == 0 ? cfg.first_block : 0, N, tid);
+        budget = admm_only ? 0 : (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
+      }
+      const bool last = kind != R_ADMM || s.iters >= max_iter;
+      __syncthreads();
+      if (budget > 0) ok = sg_polish_round(s, cfg, Lg, ws, budget, last, N, tid);
+      if (ok == 1 && s.alpha > s.alpha_target) {   // next continuation level, from this optimum and its multipliers
+#pragma unroll
+        for (int a = 0; a < 3; ++a) keep_u[a] = Lg.uv[a];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) keep_y[i] = Lg.py[i];
+        __syncthreads();
+        if (tid == 0) { s.alpha_ok = s.alpha; s.alpha = fmax(s.alpha * 0.1, s.alpha_target); }
+        __syncthreads();
+        ok = 0; cont_retry = 0;
+        kind = R_CONT;
+        continue;
+      }
+      if (ok) break;
+      if (kind == R_CONT) {   // level not reached: back to the last accepted point and a smaller step, a few times
+        if (++cont_retry > 3) { ok = 3; break; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) Lg.pu[a] = keep_u[a];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) Lg.py[i] = keep_y[i];
+        __syncthreads();
+        if (tid == 0) s.alpha = sqrt(s.alpha_ok * s.alpha);
+        __syncthreads();
+        continue;
+      }
+      if (!admm_only && s.iters >= max_iter) break;
+      {
+        const float ratio = sg_ratio(s, Lg, Lg.ua, Lg.za, Lg.ya, N, tid);
+        if (admm_only) {
+          const float tp = (float)cfg.eps_abs + (float)cfg.eps_rel * s.resid[2], td = (float)cfg.eps_abs + (float)cfg.eps_rel * s.resid[3];
+          if (s.resid[0] <= tp && s.resid[1] <= td) ok = 2;
+          __syncthreads();
+          if (tid == 0) { s.kkt[0] = s.resid[1]; s.kkt[1] = s.resid[0]; s.kkt[2] = 0.f; }
+          if (ok || s.iters >= max_iter) break;
+        }
+        const float rtol = admm_only ? 5.f : 2.f;
+        __syncthreads();
+        if (tid == 0 && isfinite(ratio) && (ratio > rtol || ratio < 1.f / rtol)) s.rho = fminf(fmaxf(s.rho * ratio, 1e-4f), 1e4f);
+        __syncthreads();
+      }
+      ++round;
+    }
+    if (ok == 3) {   // a continuation level was not reached: the previous level's answer
+#pragma unroll
+      for (int a = 0; a < 3; ++a) Lg.uv[a] = keep_u[a];
+    }
+    // ---- outputs (src/mpc.py:265-268)
+    double f[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { f[c] = (ok == 1 || ok == 3) ? Lg.uv[c] : Lg.ua[c]; if (!Lg.stance) f[c] = 0; }
+    if (Lg.leg) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ug[(size_t)b * n + 3 * tid + c] = (TIO)f[c];
+    }
+    if (Xg) {
+      double g3[3];
+      sg_grad(s, Lg, f, g3, N, tid);   // leaves the deviation states of f in s.zst
+      const double d = s.delta, th = s.theta, g = s.x0[12];
+      for (int i = tid; i < NX; i += SG_NT) {
+        const int k = i / 13, c = i - 13 * k;
+        double v;
+        if (c == 12 || k == 0) v = s.x0[c];
+        else if (c < 3) v = s.x0[c] + (double)k * d * s.rzw0[c] + s.zst[12 * k + c];
+        else if (c < 6) {
+          v = s.x0[c] + (double)k * d * s.x0[6 + c] + s.zst[12 * k + c];
+          if (c == 5) v += d * d * g * ((double)(k * (k - 1)) * 0.5 + th * (double)k);
+        } else if (c < 9) {
+          const double ax = s.zst[12 * k + 6], ay = s.zst[12 * k + 7], az = s.zst[12 * k + 8];
+          v = s.x0[c] + (c == 6 ? s.cy * ax + s.sy * ay : (c == 7 ? -s.sy * ax + s.cy * ay : az));   // omega = Rz'(Rz omega)
+        } else {
+          v = s.x0[c] + s.zst[12 * k + 6 + (c - 6)];
+          if (c == 11) v += (double)k * d * g;
+        }
+        Xg[(size_t)b * NX + i] = (TIO)v;
+      }
+    }
+    if (tid == 0) {
+      statusg[b] = ok == 1 ? MPCQP_STATUS_SOLVED_POLISHED : (ok == 2 ? MPCQP_STATUS_SOLVED_ADMM : MPCQP_STATUS_MAX_ITER);
+      itersg[b] = s.iters + 1000 * s.psteps;
+      if (resg) { resg[2 * b] = s.kkt[1]; resg[2 * b + 1] = fmaxf(s.kkt[2], s.kkt[0]); }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace

@@ -74,6 +74,8 @@ struct SmemW {
   float gmax, rho, ratio;
   int iters, psteps, hard, warm, bad;
   unsigned chgmask[(Geo::NL + 31) / 32];   // four waves per QP: leg-stages whose active set changed (polish)
+  unsigned ahash;                          // hash of the active set being filed (polish: cycle detection)
+  unsigned ahist[32];                      // ... and of the active sets this round has already tried
   uint8_t ct[Geo::NL];
   uint8_t aset[Geo::NL];         // active set of the current polish step (ActSet code)
 };
@@ -757,6 +759,7 @@ constexpr double ALPHA_FLOOR = 3e-6;    // where a request for alpha = 0 ends (t
 #ifndef MPCQP_W_POLISH_PATIENCE
 #define MPCQP_W_POLISH_PATIENCE 1
 #endif
+constexpr int POLISH_CHEAP_STEPS = 0;   // further steps of a round beyond the patience rule while they only update the inverse
 constexpr int POLISH_PATIENCE = MPCQP_W_POLISH_PATIENCE;   // polish steps that may fail to halve the KKT violation before the round gives up
 #ifndef MPCQP_W_ADAPT_AT
 #define MPCQP_W_ADAPT_AT 25
@@ -963,6 +966,21 @@ __device__ __forceinline__ int w_polish_rule(const SmemW<TV, N>& s, const int L,
   return (zs + 1) | ((xs + 1) << 2) | ((ys + 1) << 4);
 }
 
+// Hash of the active set in s.aset (order-independent sum of per-leg-stage terms, so the result does not depend on arrival order).
+// A primal-dual active-set iteration that returns to a set it has already tried repeats itself from there on: the round ends.
+// Needs s.aset visible; uniform result; ends with a sync.
+template <typename TV, int N>
+__device__ __forceinline__ unsigned w_aset_hash(SmemW<TV, N>& s, const int tid) {
+  constexpr int NL = WG<N>::NL, NW = WG<N>::NW;
+  if (tid == 0) s.ahash = 0u;
+  wsync<NW>();
+  if (tid < NL) atomicAdd(&s.ahash, ((unsigned)s.aset[tid] + 1u) * (2654435761u * (unsigned)(2 * tid + 1)));
+  wsync<NW>();
+  const unsigned h = (unsigned)__builtin_amdgcn_readfirstlane((int)s.ahash);
+  wsync<NW>();
+  return h;
+}
+
 #ifndef MPCQP_W_INCR_LEGS
 #define MPCQP_W_INCR_LEGS 8     // leg-stages whose active set may change for the inverse to be updated instead of rebuilt
 #endif
@@ -985,7 +1003,8 @@ __device__ __forceinline__ int w_polish_rule(const SmemW<TV, N>& s, const int L,
 // and MPCQP_W_INCR_STEPS updates in a row; a candidate from a drifted inverse would simply fail the KKT test.
 template <typename TV, typename TP, int N>
 __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tabs, const TP* __restrict__ kinvT, const int tid0,
-                                              const int budget, const bool last, const int trace_tag, const int incr_legs) {
+                                              const int budget, const bool last, const int trace_tag, const int incr_legs,
+                                              const int patience, const int cheap_steps) {
   constexpr int NL = WG<N>::NL, NW = WG<N>::NW, G = WG<N>::G;
   constexpr int STG = 2 * 21 + 1;   // staging record of a changed leg-stage in s.E: removed | added {A[3][6], weight[3]}, stage index
   static_assert(STG * MPCQP_W_INCR_LEGS <= N * 36, "the staging records share the bytes of E");
@@ -999,8 +1018,10 @@ __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tab
     const int code = w_polish_rule<TV, N>(s, L, s.ct[L] != 0);
     if (tid < NL) s.aset[L] = (uint8_t)code;
     wsync<NW>();
+    const unsigned h0 = w_aset_hash<TV, N>(s, tid);
+    if (tid == 0) s.ahist[0] = h0;
   }
-  int ok = 0, ps = 0;
+  int ok = 0, ps = 0, nstall = 0, cheap_used = 0;
   float vprev = INFINITY, vprev2 = INFINITY;
   bool done = false;
   while (!done) {
@@ -1142,8 +1163,9 @@ __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tab
         const bool one_sided = fminf(s.kkt[1], s.kkt[2]) <= 1e-9f;
         const bool stalled = !(v < 0.5f * vprev);
         const bool alternating = one_sided && psd >= 2 && psd < 4 && v < 0.5f * vprev2;
-        if (psd >= POLISH_PATIENCE && stalled && !alternating && !last) { done = true; break; }   // uniform
+        if (psd >= 1 && stalled && !alternating) ++nstall;
       }
+      // (the decision is taken below, once it is known whether the next step would be a cheap one)
       vprev2 = vprev; vprev = v;
       // ---- the next step's active set; what changed is staged for an update of the inverse
       int nupd = 0;
@@ -1195,7 +1217,24 @@ __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tab
         }
         if (tid < NL) s.aset[L] = (uint8_t)code;
         wsync<NW>();
+        {   // an active set this round has already tried: the iteration would repeat itself from here on
+          const unsigned h = w_aset_hash<TV, N>(s, tid);
+          bool seen = false;
+          for (int k = 0; k < min(ps, 32); ++k) seen = seen || s.ahist[k] == h;
+          if (tid == 0 && ps < 32) s.ahist[ps] = h;
+          wsync<NW>();
+          if (seen) { done = true; break; }   // uniform
+        }
+        // ... and a round whose steps have stopped making progress ends -- unless the next step is a cheap one (its active set
+        // differs on few leg-stages, so -S^-1 is updated, not rebuilt: ~4 us against the ~85 us of another ADMM round; the hardest
+        // QP of the bench batch repeated the same two candidates in three rounds, one step short of its optimum each time,
+        // tools/hardest.py), for up to `cheap_steps` such steps per round.
+        if (nstall >= patience && !last) {
+          if (incr && cheap_used < cheap_steps) ++cheap_used;
+          else { done = true; break; }   // uniform
+        }
       }
+      if (done) break;
       if (!incr) break;   // rebuild for the new active set (outer loop)
       {   // ---- -S^-1 updated term by term:  S' = S + w a a'  =>  -S'^-1 = -S^-1 + w / (1 + w a'y) y y',  y = S^-1 a
         const int tid = fresh_tid<NW>(tid0), gr = tid / G, gc = tid % G;
@@ -1336,7 +1375,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       b = (size_t)__builtin_amdgcn_readfirstlane(ob.list[(size_t)cls * ob.cap + at]);
     }
 #ifdef MPCQP_STAMPS
-    const unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();   // the 100 MHz constant clock: comparable across CUs and XCDs
 #endif
 #ifdef MPCQP_LDS_POISON   // diagnostic build: every QP starts from an LDS block full of NaN patterns (finds reads of stale LDS)
     {
@@ -1401,7 +1440,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
 #else
       const int trace_tag = -1;
 #endif
-      if (budget > 0) ok = __builtin_amdgcn_readfirstlane(w_polish_round<TV, TP, N>(s, tabs, kinvP, tid0, budget, last, trace_tag, cfg.incr_legs));
+      if (budget > 0) ok = __builtin_amdgcn_readfirstlane(w_polish_round<TV, TP, N>(s, tabs, kinvP, tid0, budget, last, trace_tag, cfg.incr_legs, cfg.patience, cfg.cheap_steps));
       if (ok == 1 && s.alpha > s.alpha_target) {   // next continuation level, from this optimum and its multipliers
         const int tid = fresh_tid<NW>(tid0);
         for (int i = tid; i < n; i += NT) s.ua[i] = s.uv[i];            // the last accepted answer and its multipliers (the ADMM
@@ -1450,7 +1489,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       unsigned hw, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      g_timeline[3 * b] = tl_t0; g_timeline[3 * b + 1] = __builtin_amdgcn_s_memtime();
+      g_timeline[3 * b] = tl_t0; g_timeline[3 * b + 1] = __builtin_amdgcn_s_memrealtime();
       g_timeline[3 * b + 2] = ((unsigned long long)xcc << 32) | hw;
     }
 #endif
