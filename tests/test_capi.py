@@ -90,6 +90,6 @@ def test_bad_config_rejected(oracle_lib):
     with pytest.raises(mpcqp.MpcQpError):
         mpcqp.Engine(oracle_lib, cfg)
     plib = mpcqp.product_library()
-    for kw in (dict(N=7), dict(precision=9), dict(relax=2.5), dict(delta=-1.0), dict(disc=5)):
+    for kw in (dict(N=0), dict(N=65), dict(precision=9), dict(relax=2.5), dict(delta=-1.0), dict(disc=5)):
         with pytest.raises(mpcqp.MpcQpError, match="-1"):
             mpcqp.Engine(plib, plib.default_config(**kw))
