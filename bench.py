@@ -4,8 +4,12 @@
 One "step" = one pass of the hot path (raw operator tuple -> solved ground-reaction forces: model build,
 discretisation, condensing, matrix inversion, ADMM, polish) over one resident batch of 4096 synthetic QPs
 (mixed gaits + friction sweep, seed 20250809 + rank).  Inputs and outputs stay
-in HBM for the whole timed region.  N>1: the batch axis is sharded, one rank per GPU, no data-path collective
-(weak scaling: 4096 QPs per GPU); `--allgather` adds the optional RCCL all-gather of stage-0 GRFs.
+in HBM for the whole timed region.  N>1: the batch axis is sharded, one rank per GPU, no data-path collective.  Two modes:
+  weak   (default)            4096 QPs per GPU, every rank its own draw (seed + rank); `--same-shards`: every rank the configured batch
+  strong (--global-batch G)   BASELINE configs[3]: G QPs of the config-4 distribution (seed 20250810) sharded contiguously over the
+                              ranks (mpcqp.dist.shard_bounds), value = G x steps / time
+`--allgather` adds the optional RCCL all-gather of stage-0 GRFs.  The per-rank times (min / mean / max) are reported next to the
+job time (= the slowest rank), so the spread between draws is visible.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the solve kernel against the packed-fp32 vector peak (the roof that
 binds: the path is neither HBM- nor MFMA-shaped) with the ALGORITHMIC flop count of SURVEY.md section
@@ -177,7 +181,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="QPs per GPU")
     ap.add_argument("--precision", default="mixed", choices=["f32", "mixed", "f64"])
     ap.add_argument("--allgather", action="store_true", help="all-gather stage-0 GRFs over RCCL every step")
-    ap.add_argument("--distinct-shards", action="store_true", help="N > 1: every rank draws its own batch (seed + rank) instead of the configured one")
+    ap.add_argument("--distinct-shards", action="store_true", help="(default since round 3; kept for old command lines)")
+    ap.add_argument("--same-shards", action="store_true", help="N > 1, weak mode: every rank solves the configured batch (seed 20250809) instead of its own draw")
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: this many QPs in total (config-4 distribution), sharded contiguously over the ranks")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the secondary per-gait / all-stance figures")
@@ -211,10 +217,19 @@ def main():
 
     N, delta, B = 10, 0.03, args.batch
     gaits, mus = ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0)
-    # this rank's shard.  Weak scaling = the same work on every GPU: each rank solves the configured batch itself (same seed); with
-    # --distinct-shards each rank draws its own (seed + rank) -- then the job is as slow as the unluckiest draw (a launch of 4096 is
-    # as long as its longest QPs: +-15 % between seeds), which says nothing about the GPUs.
-    batch = mpcqp.synth.make_batch(B, N, delta, 20250809 + (rank if args.distinct_shards else 0), gaits, mus)
+    # this rank's shard.  Weak scaling: 4096 QPs per GPU, each rank its own draw of the workload (seed + rank; rank 0 = the configured
+    # batch) -- a launch of 4096 is as long as its longest QPs, so the ranks' times differ by the draw (reported below), and the job
+    # is as slow as the unluckiest one.  Strong scaling (--global-batch): BASELINE configs[3], the batch sharded contiguously.
+    strong = args.global_batch > 0
+    if strong:
+        from mpcqp.dist import shard_bounds
+        lo, hi = shard_bounds(args.global_batch, world, rank)
+        full = mpcqp.synth.make_batch(args.global_batch, N, delta, 20250810, gaits, mus)
+        batch = {k: (v[lo:hi] if isinstance(v, np.ndarray) and len(v) == args.global_batch else v) for k, v in full.items()}
+        B = hi - lo
+        del full
+    else:
+        batch = mpcqp.synth.make_batch(B, N, delta, 20250809 + (0 if args.same_shards else rank), gaits, mus)
     # (MPCQP_FLAG_NO_TIMING: the engine's own per-call event pair is a diagnostic; the timed region below is bracketed by this
     #  script's events on the same stream)
     solver = mpcqp.MPCBatch(N=N, delta=delta, device=device_index, io_dtype="f32", precision=args.precision,
@@ -224,11 +239,16 @@ def main():
     if args.allgather and dist is not None:   # RCCL: device buffers over xGMI; gloo (1-GPU rehearsals): through host memory
         gathered = torch.empty((world * B, 12), dtype=torch.float32, device=solver.device if backend == "nccl" else "cpu")
 
+    ragged = strong and args.global_batch % world != 0
+
     def step():
         out = solver.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"], want_X=False)
         if gathered is not None:
-            u0 = out["u"][:, 0, :].contiguous()
-            dist.all_gather_into_tensor(gathered, u0 if backend == "nccl" else u0.cpu())
+            if ragged:       # unequal shards: padded gather (mpcqp.dist)
+                mpcqp.dist.all_gather_stage0(out["u"] if backend == "nccl" else out["u"].cpu(), args.global_batch)
+            else:
+                u0 = out["u"][:, 0, :].contiguous()
+                dist.all_gather_into_tensor(gathered, u0 if backend == "nccl" else u0.cpu())
         return out
 
     for _ in range(args.warmup):
@@ -250,13 +270,17 @@ def main():
     kernel_ms = evs[0].elapsed_time(evs[-1]) / args.steps       # average launch duration over the timed region
     step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2]
+    rank_ms = [kernel_ms]
+    total_qps = B
     if dist:
-        t = torch.tensor([dt, kernel_ms], dtype=torch.float64, device=sync_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)     # the job is as slow as its slowest rank
-        dt, kernel_ms = float(t[0].item()), float(t[1].item())
-        agg = torch.tensor([float(((out["status"] == 1) | (out["status"] == 2)).sum().item())], dtype=torch.float64, device=sync_device)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        solved_all = float(agg.item()) / (world * B)
+        mine = torch.tensor([dt, kernel_ms, float(B), float(((out["status"] == 1) | (out["status"] == 2)).sum().item())], dtype=torch.float64, device=sync_device)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().numpy()
+        dt, kernel_ms = float(allr[:, 0].max()), float(allr[:, 1].max())     # the job is as slow as its slowest rank
+        rank_ms = [float(v) for v in allr[:, 1]]
+        total_qps = int(allr[:, 2].sum())
+        solved_all = float(allr[:, 3].sum()) / total_qps
 
     status = out["status"].cpu().numpy()
     iters = out["iters"].cpu().numpy()
@@ -265,7 +289,7 @@ def main():
         solved = solved_all
     k_mean = float((iters % 1000).mean())
     if rank == 0:
-        value = world * B * args.steps / dt
+        value = total_qps * args.steps / dt
         flops = algorithmic_flops(N, k_mean)
         achieved = flops * B / (kernel_ms * 1e-3) / 1e12
         hbm = algorithmic_bytes(N) * B / (kernel_ms * 1e-3) / 1e9
@@ -297,11 +321,14 @@ def main():
             "metric": "QP solves/sec (horizon=10, 4-contact Lite3) at batch=4096", "value": value, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "ms_per_step_median": median_ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "rank_kernel_ms": {"min": min(rank_ms), "mean": sum(rank_ms) / len(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
             "dtype": {"f32": "f32", "mixed": "f32 tiles + f64 residuals", "f64": "f64"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "configs[2]: batch=4096/GPU mixed gaits (trot/pronk/amble/gallop) + mu sweep, horizon=10, "
-                                   "dt=0.03, Lite3 constants, alpha=1e-2, euler", "batch_per_gpu": B, "shards": "distinct (seed + rank)" if args.distinct_shards else "every rank solves the configured batch", "horizon": N,
+                                   "dt=0.03, Lite3 constants, alpha=1e-2, euler", "batch_per_gpu": B, "global_batch": total_qps,
+                       "shards": ("contiguous shards of one batch of %d (seed 20250810)" % args.global_batch) if strong else
+                                 ("every rank solves the configured batch" if args.same_shards else "one draw per rank (seed 20250809 + rank)"), "horizon": N,
                        "precision": args.precision, "admm_block": int(solver.cfg.check_every), "max_iter": int(solver.cfg.max_iter),
                        "polish": bool(solver.cfg.flags & 1), "allgather": bool(gathered is not None),
                        "solved_fraction": solved, "admm_iters_mean": k_mean, "polish_steps_mean": float((iters // 1000).mean())},

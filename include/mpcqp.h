@@ -184,14 +184,25 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
  *   footholds T  [B,2,4,3]  plan[step]['pos'] of the current and of the next step (src/mpc.py:306-318)
  *   gait      i32[B,4]      ticks elapsed in the current step, ss_duration, ds_duration, reserved (0)
  *   feet_id   u8 [B,2,4]    plan[step]['feet_id'] of the current and of the next step (1 = stance during single support)
- * Stage k uses step 0 while t_in_step + k < ss + ds, else step 1; N must not exceed ss + ds so that the horizon spans at
- * most two steps (mpcqp_rollout takes whole plan tables and has no such limit).  The descriptors are expanded by an
- * element-wise pre-pass into an engine-owned tuple workspace, then solved exactly as mpcqp_solve_batch would.  Outputs as
- * mpcqp_solve_batch.  Product library: horizon 10; otherwise MPCQP_EINVAL.
+ * Stage k lies in step min((t_in_step + k) / (ss + ds), S - 1) of the descriptor, S = 2 here: a horizon that runs past the last
+ * described step stays in it with its time running on, i.e. all feet in stance (the planner's own clamp at the end of a plan,
+ * src/footstep_planner.py:226-237) -- describe as many steps as the horizon spans (mpcqp_solve_batch_gait_steps) to avoid that.
+ * The descriptors are expanded by an element-wise pre-pass into an engine-owned tuple workspace, then solved exactly as
+ * mpcqp_solve_batch would.  Outputs as mpcqp_solve_batch.  Any horizon.
  */
 int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void* ref, const void* feet0,
                            const void* footholds, const int32_t* gait, const uint8_t* feet_id, const void* mu,
                            void* u_out, void* X_out, int32_t* status, int32_t* iters, float* res, void* stream);
+
+/*
+ * The same with S >= 1 plan steps per robot: footholds T [B,S,4,3], feet_id u8 [B,S,4] (plan[step + s]['pos'] / ['feet_id'] for
+ * s = 0..S-1).  A horizon of N stages starting t_in_step ticks into a step of ss + ds ticks spans
+ * ceil((t_in_step + N) / (ss + ds)) steps: 5 for the reference's own N = 60 with 15-tick steps (src/main.py:35-37).
+ * Negative durations / ticks are clamped to 0 and ss + ds to at least 1.
+ */
+int mpcqp_solve_batch_gait_steps(mpcqp_handle h, int64_t B, int32_t S, const void* x0, const void* ref, const void* feet0,
+                                 const void* footholds, const int32_t* gait, const uint8_t* feet_id, const void* mu,
+                                 void* u_out, void* X_out, int32_t* status, int32_t* iters, float* res, void* stream);
 
 /*
  * Closed-loop roll-out: B robots advance T control ticks on the device -- per tick the parameter fill of MPC.solve

@@ -26,7 +26,7 @@ FLAG_STAGE_KERNEL = 128
 
 EXPORTED_SYMBOLS = (
     "mpcqp_version", "mpcqp_default_config", "mpcqp_create", "mpcqp_destroy", "mpcqp_solve_batch",
-    "mpcqp_solve_batch_gait", "mpcqp_torque_map", "mpcqp_last_kernel_ms", "mpcqp_last_error", "mpcqp_reserve", "mpcqp_rollout",
+    "mpcqp_solve_batch_gait", "mpcqp_solve_batch_gait_steps", "mpcqp_torque_map", "mpcqp_last_kernel_ms", "mpcqp_last_error", "mpcqp_reserve", "mpcqp_rollout",
 )
 
 
@@ -79,6 +79,8 @@ class Library:
         L.mpcqp_solve_batch.restype = c_int32
         L.mpcqp_solve_batch_gait.argtypes = [c_void_p, c_int64] + [c_void_p] * 13
         L.mpcqp_solve_batch_gait.restype = c_int32
+        L.mpcqp_solve_batch_gait_steps.argtypes = [c_void_p, c_int64, c_int32] + [c_void_p] * 13
+        L.mpcqp_solve_batch_gait_steps.restype = c_int32
         L.mpcqp_torque_map.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
         L.mpcqp_torque_map.restype = c_int32
         L.mpcqp_last_kernel_ms.argtypes = [c_void_p, ctypes.POINTER(c_float)]
@@ -162,6 +164,13 @@ class Engine:
         if rc != 0:
             raise MpcQpError(f"mpcqp_solve_batch_gait failed with code {rc}: {self.last_error()}")
 
+    def solve_batch_gait_steps_ptr(self, B, S, x0, ref, feet0, footholds, gait, feet_id, mu, u_out, X_out, status, iters, res, stream=0):
+        """Raw call of the gait entry point with S plan steps per robot (footholds [B,S,4,3], feet_id [B,S,4])."""
+        rc = self.library.lib.mpcqp_solve_batch_gait_steps(self._h, int(B), int(S), x0, ref, feet0, footholds, gait, feet_id, mu, u_out,
+                                                           X_out or None, status, iters, res or None, stream or None)
+        if rc != 0:
+            raise MpcQpError(f"mpcqp_solve_batch_gait_steps failed with code {rc}: {self.last_error()}")
+
     def rollout_ptr(self, B, T, S, x, ref, plan_pos, plan_feet_id, plan_meta, tick, mu, actual, desired, forces, solved, stream=0):
         """Raw call of the closed-loop roll-out (include/mpcqp.h, mpcqp_rollout); every argument is an integer address."""
         rc = self.library.lib.mpcqp_rollout(self._h, int(B), int(T), int(S), x, ref, plan_pos, plan_feet_id, plan_meta, tick, mu,
@@ -213,17 +222,17 @@ class Engine:
 
 
     def solve_batch_gait_host(self, g, want_X=True):
-        """Host-pointer convenience for the gait entry point; `g` is a dict as produced by synth.make_gait_batch."""
+        """Host-pointer convenience for the gait entry point; `g` is a dict as produced by synth.make_gait_batch (footholds [B,S,4,3])."""
         N = self.cfg.N
         ft = np.float64 if self.cfg.dtype == DTYPE_F64 else np.float32
         a = {k: np.ascontiguousarray(g[k], dtype=ft) for k in ("x0", "ref", "feet0", "footholds", "mu")}
         gait = np.ascontiguousarray(g["gait"], dtype=np.int32); fid = np.ascontiguousarray(g["feet_id"], dtype=np.uint8)
-        B = a["x0"].shape[0]
+        B, S = a["x0"].shape[0], a["footholds"].shape[1]
         u = np.zeros((B, N, 12), ft); X = np.zeros((B, N + 1, 13), ft) if want_X else None
         status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); res = np.zeros((B, 2), np.float32)
-        self.solve_batch_gait_ptr(B, a["x0"].ctypes.data, a["ref"].ctypes.data, a["feet0"].ctypes.data, a["footholds"].ctypes.data,
-                                  gait.ctypes.data, fid.ctypes.data, a["mu"].ctypes.data, u.ctypes.data,
-                                  X.ctypes.data if want_X else None, status.ctypes.data, iters.ctypes.data, res.ctypes.data)
+        self.solve_batch_gait_steps_ptr(B, S, a["x0"].ctypes.data, a["ref"].ctypes.data, a["feet0"].ctypes.data, a["footholds"].ctypes.data,
+                                        gait.ctypes.data, fid.ctypes.data, a["mu"].ctypes.data, u.ctypes.data,
+                                        X.ctypes.data if want_X else None, status.ctypes.data, iters.ctypes.data, res.ctypes.data)
         return {"u": u, "X": X, "status": status, "iters": iters, "res": res}
 
 

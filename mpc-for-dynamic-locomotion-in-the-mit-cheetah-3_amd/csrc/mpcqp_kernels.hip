@@ -47,12 +47,14 @@ mpcqp_torque_kernel(const TIO* __restrict__ u, const TIO* __restrict__ jac, TIO*
 //   x_des[k]   = [roll0, pitch0, yaw_start + k d w, com_start + k d v, 0, 0, w, v, g]             (src/mpc.py:202-214)
 //   contact[k] = feet_id[step(k)] during that step's first ss ticks, else all stance          (footstep_planner.py:239-246)
 //   r[0]       = measured foot - measured com;  r[k>=1] = planned foothold of step(k) - x_des com(k)   (src/mpc.py:218-239)
-// with step(k) = 0 while t_in_step + k < ss + ds, else 1.  Element-wise and HBM-bound (about 100 B in, 1.1 KB out per QP, which
-// the solve kernel then reads from L2): one thread per output element, consecutive threads write consecutive addresses.
+// with step(k) = min((t_in_step + k) / (ss + ds), S - 1) over the S described steps (past the last one: that step with its time running
+// on, all feet in stance -- the planner's clamp, src/footstep_planner.py:226-237).  Element-wise and HBM-bound (about 100 B in, 1.1 KB
+// out per QP at N = 10, which the solve kernel then reads from L2): one thread per output element, consecutive threads write
+// consecutive addresses.
 template <typename TIO>
 __global__ void __launch_bounds__(256)
-mpcqp_gait_expand_kernel(const FastIn<TIO> in, const double d, const int N, const int64_t B, TIO* __restrict__ r, uint8_t* __restrict__ contact,
-                         TIO* __restrict__ xdes) {
+mpcqp_gait_expand_kernel(const FastIn<TIO> in, const double d, const int N, const int S, const int64_t B, TIO* __restrict__ r,
+                         uint8_t* __restrict__ contact, TIO* __restrict__ xdes) {
   const int nx = (N + 1) * 13, nr = N * 12, per = nx + nr;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= B * per) return;
@@ -72,14 +74,13 @@ mpcqp_gait_expand_kernel(const FastIn<TIO> in, const double d, const int N, cons
     xdes[b * nx + e] = (TIO)v;
   } else {
     const int i = e - nx, k = i / 12, l = (i % 12) / 3, a = i % 3;
-    const int tis = in.gait[b * 4 + 0], ss = in.gait[b * 4 + 1], ds = in.gait[b * 4 + 2];
-    int tau = tis + k, st = 0;
-    if (tau >= ss + ds) { tau -= ss + ds; st = 1; }
+    const int tis = max(in.gait[b * 4 + 0], 0), ss = max(in.gait[b * 4 + 1], 0), period = max(ss + max(in.gait[b * 4 + 2], 0), 1);
+    const int tau = tis + k, st = min(tau / period, S - 1), tin = tau - st * period;
     double v;
     if (k == 0) v = (double)in.feet0[b * 12 + l * 3 + a] - (double)in.x0[b * 13 + 3 + a];
-    else v = (double)in.footholds[b * 24 + st * 12 + l * 3 + a] - ((double)ref[3 + a] + (double)k * d * (double)ref[6 + a]);
+    else v = (double)in.footholds[((b * S + st) * 4 + l) * 3 + a] - ((double)ref[3 + a] + (double)k * d * (double)ref[6 + a]);
     r[b * nr + i] = (TIO)v;
-    if (a == 0) contact[b * (N * 4) + k * 4 + l] = (tau < ss) ? (in.feet_id[b * 8 + st * 4 + l] ? 1 : 0) : 1;
+    if (a == 0) contact[b * (N * 4) + k * 4 + l] = (tin < ss) ? (in.feet_id[(b * S + st) * 4 + l] ? 1 : 0) : 1;
   }
 }
 
@@ -671,15 +672,14 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
   return MPCQP_OK;
 }
 
-int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void* ref, const void* feet0, const void* footholds,
-                           const int32_t* gait, const uint8_t* feet_id, const void* mu, void* u_out, void* X_out,
-                           int32_t* status, int32_t* iters, float* res, void* stream) {
+int mpcqp_solve_batch_gait_steps(mpcqp_handle h, int64_t B, int32_t S, const void* x0, const void* ref, const void* feet0, const void* footholds,
+                                 const int32_t* gait, const uint8_t* feet_id, const void* mu, void* u_out, void* X_out,
+                                 int32_t* status, int32_t* iters, float* res, void* stream) {
   if (!h) return MPCQP_EINVAL;
+  if (S < 1) return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait_steps: at least one plan step");
   if (B < 0 || B > 0x7fffffff) return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: batch size out of range");
   if (B > 0 && (!x0 || !ref || !feet0 || !footholds || !gait || !feet_id || !mu || !u_out || !status || !iters))
     return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: null buffer");
-  if (h->cfg.N != 10 || !(wrench_path_applies(h) || fast_path_applies(h)))
-    return fail(h, MPCQP_EINVAL, "mpcqp_solve_batch_gait: needs N = 10, polish, alpha > 0");
   if (B == 0) return mpcqp_solve_batch(h, 0, x0, nullptr, nullptr, nullptr, mu, u_out, X_out, status, iters, res, stream);
   DeviceGuard guard(h->cfg.device);
   if (guard.err != hipSuccess) return fail(h, MPCQP_EHIP, "hipSetDevice", guard.err);
@@ -697,16 +697,22 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void
   if (h->cfg.dtype == MPCQP_DTYPE_F64) {
     const FastIn<double> in = {(const double*)x0, nullptr, nullptr, nullptr, (const double*)mu, (const double*)ref, (const double*)feet0,
                                (const double*)footholds, gait, feet_id, nullptr, nullptr, 0};
-    hipLaunchKernelGGL((mpcqp_gait_expand_kernel<double>), grid, dim3(256), 0, st, in, h->cfg.delta, (int)N, B, (double*)r, contact, (double*)xdes);
+    hipLaunchKernelGGL((mpcqp_gait_expand_kernel<double>), grid, dim3(256), 0, st, in, h->cfg.delta, (int)N, (int)S, B, (double*)r, contact, (double*)xdes);
   } else {
     const FastIn<float> in = {(const float*)x0, nullptr, nullptr, nullptr, (const float*)mu, (const float*)ref, (const float*)feet0,
                               (const float*)footholds, gait, feet_id, nullptr, nullptr, 0};
-    hipLaunchKernelGGL((mpcqp_gait_expand_kernel<float>), grid, dim3(256), 0, st, in, h->cfg.delta, (int)N, B, (float*)r, contact, (float*)xdes);
+    hipLaunchKernelGGL((mpcqp_gait_expand_kernel<float>), grid, dim3(256), 0, st, in, h->cfg.delta, (int)N, (int)S, B, (float*)r, contact, (float*)xdes);
   }
   const hipError_t he = hipGetLastError();
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "gait expansion kernel launch", he);
   h->ev0_set = true;   // the solve's timing starts in front of the expansion
   return mpcqp_solve_batch(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, stream);
+}
+
+int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0, const void* ref, const void* feet0, const void* footholds,
+                           const int32_t* gait, const uint8_t* feet_id, const void* mu, void* u_out, void* X_out,
+                           int32_t* status, int32_t* iters, float* res, void* stream) {
+  return mpcqp_solve_batch_gait_steps(h, B, 2, x0, ref, feet0, footholds, gait, feet_id, mu, u_out, X_out, status, iters, res, stream);
 }
 
 int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* x, void* ref, const void* plan_pos, const uint8_t* plan_feet_id,

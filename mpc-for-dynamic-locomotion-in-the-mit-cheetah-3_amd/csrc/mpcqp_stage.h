@@ -18,10 +18,11 @@
 // live in that lane's registers for the whole solve (no register tile exists here), stage sums are two DPP quad steps, and LDS
 // holds only the wrench-space vectors (6 N) and the recursion's states (12 N).  The two serial recursions of a solve run on ONE
 // group of 8 lanes -- lane c holds (P_c, Q_c) of wrench component c, the 6-vectors they need from each other are gathered with
-// DPP butterflies (lane ^ 1, ^ 2, ^ 3 by quad_perm, ^ 7 by row_half_mirror), no LDS on the critical path -- from per-stage factor
-// matrices that are stored in that butterfly order in a global-memory workspace (2.6 KB fp32 / 5.2 KB fp64 per stage: too large
-// for LDS at 64 stages) and prefetched one stage ahead; everything that does not depend on the recursion's carry (Pi+ Gam b_k,
-// E_k Gam' pi_{k+1}, y_k) is done by all lanes in parallel before / between / after the two chains.
+// DPP butterflies (lane ^ 1, ^ 2, ^ 3 by quad_perm, ^ 7 by row_half_mirror) -- from per-stage factor matrices stored in that
+// butterfly order and read from LDS one stage ahead (fp32: resident for the whole ADMM block; fp64: 64 KB per direction, copied
+// from a global-memory workspace in front of each chain), so that nothing on the recursion's critical path waits for memory;
+// everything that does not depend on the recursion's carry (Pi+ Gam b_k, E_k Gam' pi_{k+1}, y_k) is done by all lanes in parallel
+// before / between / after the two chains.
 // The factorisation itself always runs in fp64 (wave 0, 6 x 6 inverses in LDS); the ADMM chains use its fp32 rounding in the
 // MIXED precision and fp64 in F64; the polish is all fp64.
 #pragma once
@@ -32,9 +33,9 @@ namespace {
 constexpr int SG_NS = 64;                 // stages a workgroup can hold
 constexpr int SG_NT = 256, SG_NW = 4;     // one lane per leg-stage
 constexpr int SG_NQ = 6 * SG_NS;
-// Workspace of one resident workgroup, in doubles: per stage  E (36, fp64) | Lrow (128 TM) | Lcol (128 TM) | PG (72 TM); the TM
-// parts are sized for fp64.
-constexpr int SG_WS_STAGE = 36 + 128 + 128 + 72;
+// Workspace of one resident workgroup, in doubles: the fp64 chains' factor matrices, per stage  Lrow (128) | Lcol (128)  (the fp32
+// chains keep theirs in LDS for the whole ADMM block).
+constexpr int SG_WS_STAGE = 128 + 128;
 constexpr size_t SG_WS_DOUBLES = (size_t)SG_NS * SG_WS_STAGE;
 
 struct SmemS {
@@ -42,10 +43,14 @@ struct SmemS {
   double mu, cy, sy, rzw0[3], wP[6], wQ[6], delta, theta, alpha, inv_m, fmin, fmax, alpha_target, alpha_ok;
   double gam[SG_NQ];                   // gradient of the cost in wrench space at u = 0
   double ww[SG_NQ], kap[SG_NQ];        // wrench of the structured gradient's point, K ww + gam
-  double bq[SG_NQ], yq[SG_NQ];         // S y = b
-  double s0[SG_NS * 12];               // Pi+ Gam b_k (backward half), then d_k = b_k - E_k Gam' pi_{k+1} (forward half); setup: e0
-  double pist[(SG_NS + 1) * 12];       // pi_k, k = 1..N (index k); setup: x_des staging (with zst)
-  double zst[(SG_NS + 1) * 12];        // z_k, k = 0..N; structured gradient: the deviation states of its point
+  double bq[SG_NQ];                    // S y = b: the right-hand side (wrench space)
+  // The recursion's vectors, 12 per stage in chain order: component c at [12 k + 2 c] (P) and [12 k + 2 c + 1] (Q), so that chain lane c
+  // moves its pair with one LDS access (+ 4: lanes 6, 7 of the chain group read past the last stage and mask the value).
+  alignas(16) double s0[SG_NS * 12 + 4];        // Pi+ Gam b_k (backward half), then d_k (forward half, P slots); setup: e0 (own layout)
+  alignas(16) double pist[(SG_NS + 1) * 12];    // pi_k, k = 1..N (index k); setup: x_des staging (with zst)
+  alignas(16) double zst[(SG_NS + 1) * 12];     // z_k, k = 0..N; structured gradient: the deviation states of its point (own layout)
+  double PGs[SG_NS * 72];              // Pi+ Gam per stage (12 x 6, rows P_0..P_5, Q_0..Q_5), written by the factorisation
+  double Es[SG_NS * 36];               // E_k = T D^-1 T' per stage
   // factorisation scratch (wave 0)
   double Pi[144], PG[72], Ps[36], Pinv[36], Zm[36], T1[36], Eh[36], Lm[72], Ek[36];
   float red[SG_NW * 4];
@@ -118,9 +123,9 @@ __device__ __forceinline__ void sg_mm6(double* __restrict__ C, const double* __r
   wsync<1>();
 }
 
-// Riccati factorisation for the E_k blocks in the workspace (fp64), by wave 0; the other waves wait at the closing barrier.
-// Writes per stage, in TM: Lrow / Lcol (the rows / columns of L = Pi+ Gam Ehat in the butterfly order of the two chains) and
-// PG = Pi+ Gam.  kmin: stages below it keep the factors they have (unused: every call refactors all stages).
+// Riccati factorisation for the E_k blocks in s.Es (fp64), by wave 0; the other waves wait at the closing barrier.
+// Writes per stage: Lrow / Lcol (the rows / columns of L = Pi+ Gam Ehat in the butterfly order of the two chains; fp32 -> LDS,
+// fp64 -> workspace) and PG = Pi+ Gam (LDS).
 template <typename TM>
 __device__ __forceinline__ void sg_factor(SmemS& s, double* __restrict__ ws, const int N, const int tid) {
   if (tid < 64) {
@@ -128,14 +133,10 @@ __device__ __forceinline__ void sg_factor(SmemS& s, double* __restrict__ ws, con
     const double d = s.delta, th = s.theta, gp = th * d * d, gq = d;   // Gam = [gp I ; gq I]
     for (int e = lane; e < 144; e += 64) { const int i = e / 12, j = e - 12 * i; s.Pi[e] = i == j ? 2.0 * (i < 6 ? s.wP[i] : s.wQ[i - 6]) : 0.0; }
     wsync<1>();
-    double e_next = lane < 36 ? ws[(size_t)(N - 1) * SG_WS_STAGE + lane] : 0.0;
 #pragma unroll 1
     for (int k = N - 1; k >= 0; --k) {
-      double* wk = ws + (size_t)k * SG_WS_STAGE;
-      TM* fac = reinterpret_cast<TM*>(wk + 36);
-      const double e_cur = e_next;
-      if (k > 0 && lane < 36) e_next = ws[(size_t)(k - 1) * SG_WS_STAGE + lane];
-      if (lane < 36) s.Ek[lane] = e_cur;
+      double* fac = ws + (size_t)k * SG_WS_STAGE;
+      if (lane < 36) s.Ek[lane] = s.Es[36 * k + lane];
       // PG = Pi Gam (12 x 6)
       for (int e = lane; e < 72; e += 64) { const int i = e / 6, c = e - 6 * i; s.PG[e] = gp * s.Pi[12 * i + c] + gq * s.Pi[12 * i + 6 + c]; }
       wsync<1>();
@@ -171,11 +172,11 @@ __device__ __forceinline__ void sg_factor(SmemS& s, double* __restrict__ ws, con
           reinterpret_cast<float*>(s.fbuf)[128 * k + e] = lr;
           reinterpret_cast<float*>(s.fbuf)[SG_NS * 128 + 128 * k + e] = lc;
         } else {
-          fac[e] = lr;
-          fac[128 + e] = lc;
+          fac[e] = (double)lr;
+          fac[128 + e] = (double)lc;
         }
       }
-      for (int e = lane; e < 72; e += 64) fac[256 + e] = (TM)s.PG[e];
+      for (int e = lane; e < 72; e += 64) s.PGs[72 * k + e] = s.PG[e];
       // Pi <- 2W + Phi' (Pi - L PG') Phi,  symmetrised.  M = Pi - L PG' first (each lane three entries, read before any write)
       double m[3];
 #pragma unroll
@@ -219,127 +220,8 @@ __device__ __forceinline__ void sg_factor(SmemS& s, double* __restrict__ ws, con
   __syncthreads();
 }
 
-// S y = b:  s.bq -> s.yq  with the factors in the workspace.  All lanes call.
-template <typename TM>
-__device__ __forceinline__ void sg_solve(SmemS& s, const double* __restrict__ ws, const int N, const int tid) {
-  const double d = s.delta, th = s.theta, gp = th * d * d, gq = d;
-  // (a) s0_k = PG_k b_k for k = 1..N-1 (stage 0 has no pi_0)
-  for (int e = tid; e < 12 * N; e += SG_NT) {
-    const int k = e / 12, i = e - 12 * k;
-    const TM* pg = reinterpret_cast<const TM*>(ws + (size_t)k * SG_WS_STAGE + 36) + 256 + 6 * i;
-    double a = 0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) a = fma((double)pg[c], s.bq[6 * k + c], a);
-    s.s0[e] = a;
-  }
-  if (tid < 12) { s.pist[12 * N + tid] = 0.0; s.zst[tid] = 0.0; }
-  if constexpr (sizeof(TM) == 8) {   // Lrow of all stages -> LDS
-    double* fb = reinterpret_cast<double*>(s.fbuf);
-    for (int e = tid; e < 128 * N; e += SG_NT) fb[e] = ws[(size_t)(e >> 7) * SG_WS_STAGE + 36 + (e & 127)];
-  }
-  __syncthreads();
-  const TM* const frow = reinterpret_cast<const TM*>(s.fbuf);
-  const TM* const fcol = reinterpret_cast<const TM*>(s.fbuf) + (sizeof(TM) == 4 ? SG_NS * 128 : 0);
-  // (b) backward chain: group 0 of wave 0 (the other lanes of the wave run along on zeros)
-  if (tid < 64) {
-    const int c = tid & 7;
-    const bool on = tid < 6;
-    TM pp = 0, pq = 0;
-    TM Lr[16];
-    {
-      const TM* f = frow + 128 * (N - 1) + 16 * c;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) Lr[t] = f[t];
-    }
-#pragma unroll 1
-    for (int k = N - 1; k >= 1; --k) {
-      TM Ln[16];
-      {
-        const TM* f = frow + 128 * (k - 1) + 16 * c;   // (k - 1 = 0 is loaded and not used)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) Ln[t] = f[t];
-      }
-      TM sp = on ? (TM)s.s0[12 * k + c] + pp : (TM)0, sq = on ? (TM)s.s0[12 * k + 6 + c] + pq : (TM)0;
-      const TM cc = (TM)gp * sp + (TM)gq * sq;
-      TM g[8];
-      xor_gather8(cc, g);
-      TM a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { a0 = fma(Lr[t], g[t], a0); a1 = fma(Lr[4 + t], g[4 + t], a1); b0 = fma(Lr[8 + t], g[t], b0); b1 = fma(Lr[12 + t], g[4 + t], b1); }
-      sp -= a0 + a1; sq -= b0 + b1;
-      pp = sp; pq = fma((TM)d, sp, sq);
-      if (on) { s.pist[12 * k + c] = (double)pp; s.pist[12 * k + 6 + c] = (double)pq; }
-#pragma unroll
-      for (int t = 0; t < 16; ++t) Lr[t] = Ln[t];
-    }
-  }
-  __syncthreads();
-  // (c) d_k = b_k - E_k Gam' pi_{k+1}  (fp64 chains: Lcol of all stages -> LDS, the backward chain is done with Lrow)
-  if constexpr (sizeof(TM) == 8) {
-    double* fb = reinterpret_cast<double*>(s.fbuf);
-    for (int e = tid; e < 128 * N; e += SG_NT) fb[e] = ws[(size_t)(e >> 7) * SG_WS_STAGE + 36 + 128 + (e & 127)];
-  }
-  for (int e = tid; e < 6 * N; e += SG_NT) {
-    const int k = e / 6, c = e - 6 * k;
-    const double* Ek = ws + (size_t)k * SG_WS_STAGE + 6 * c;
-    const double* pk = s.pist + 12 * (k + 1);
-    double a = s.bq[e];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) a -= Ek[q] * (gp * pk[q] + gq * pk[6 + q]);
-    s.s0[12 * k + c] = a;
-  }
-  __syncthreads();
-  // (d) forward chain
-  if (tid < 64) {
-    const int c = tid & 7;
-    const bool on = tid < 6;
-    TM zp = 0, zq = 0;
-    TM Lc[16];
-    {
-      const TM* f = fcol + 16 * c;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) Lc[t] = f[t];
-    }
-#pragma unroll 1
-    for (int k = 0; k < N; ++k) {
-      TM Ln[16];
-      {
-        const TM* f = fcol + 128 * min(k + 1, N - 1) + 16 * c;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) Ln[t] = f[t];
-      }
-      const TM dk = on ? (TM)s.s0[12 * k + c] : (TM)0;
-      const TM tp = zp + (TM)d * zq + (TM)gp * dk, tq = zq + (TM)gq * dk;
-      TM g0[8], g1[8];
-      xor_gather8(tp, g0);
-      xor_gather8(tq, g1);
-      TM a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { a0 = fma(Lc[t], g0[t], a0); a1 = fma(Lc[4 + t], g0[4 + t], a1); b0 = fma(Lc[8 + t], g1[t], b0); b1 = fma(Lc[12 + t], g1[4 + t], b1); }
-      const TM o = (a0 + a1) + (b0 + b1);
-      zp = tp - (TM)gp * o; zq = tq - (TM)gq * o;
-      if (on) { s.zst[12 * (k + 1) + c] = (double)zp; s.zst[12 * (k + 1) + 6 + c] = (double)zq; }
-#pragma unroll
-      for (int t = 0; t < 16; ++t) Lc[t] = Ln[t];
-    }
-  }
-  __syncthreads();
-  // (e) y_k = PG_k' z_{k+1} + Gam' pi_{k+1}
-  for (int e = tid; e < 6 * N; e += SG_NT) {
-    const int k = e / 6, c = e - 6 * k;
-    const TM* pg = reinterpret_cast<const TM*>(ws + (size_t)k * SG_WS_STAGE + 36) + 256 + c;
-    const double* zk = s.zst + 12 * (k + 1);
-    const double* pk = s.pist + 12 * (k + 1);
-    double a = gp * pk[c] + gq * pk[6 + c];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) a = fma((double)pg[6 * i], zk[i], a);
-    s.yq[e] = a;
-  }
-  __syncthreads();
-}
-
-// E_k = sum_legs A diag(dinv) A' (fp64) -> workspace.  Leg lanes (a quad = a stage).  Ends with a barrier.
-__device__ __forceinline__ void sg_build_E(const LegSys<double>& L, double* __restrict__ ws, const bool leg, const int tid) {
+// E_k = sum_legs A diag(dinv) A' (fp64) -> LDS.  Leg lanes (a quad = a stage).  Ends with a barrier.
+__device__ __forceinline__ void sg_build_E(SmemS& s, const LegSys<double>& L, const bool leg, const int tid) {
   double e[21];
   int k = 0;
 #pragma unroll
@@ -353,7 +235,7 @@ __device__ __forceinline__ void sg_build_E(const LegSys<double>& L, double* __re
     }
   }
   if (leg && (tid & 3) == 0) {
-    double* Ej = ws + (size_t)(tid >> 2) * SG_WS_STAGE;
+    double* Ej = s.Es + 36 * (tid >> 2);
     k = 0;
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -364,29 +246,157 @@ __device__ __forceinline__ void sg_build_E(const LegSys<double>& L, double* __re
   __syncthreads();
 }
 
-// x = M^-1 rhs,  M = D + A-stack' K A-stack:  x = dinv (rhs - A' S^-1 A-stack dinv rhs).  All lanes call.
+// x = M^-1 rhs,  M = D + A-stack' K A-stack:  x = dinv (rhs - A' y),  S y = A-stack dinv rhs  by the two recursions.  All lanes call.
+//   leg lanes   a = dinv rhs,  b_k = sum_legs A a (quad sum) -> bq;  the quad's four lanes share the 12 entries of Pi+ Gam b_k -> s0
+//   chain       backward recursion (wave 0): pi_k -> pist
+//   all lanes   d_k = b_k - E_k Gam' pi_{k+1} -> s0 (P slots)
+//   chain       forward recursion: z_{k+1} -> zst
+//   leg lanes   y_k = PG_k' z_{k+1} + Gam' pi_{k+1} (two components per lane, shared over the quad by DPP),  x = a - dinv A' y_k
+// Four barriers.  The chain lanes read their pair of the NEXT step and its factor rows one step ahead; nothing in a step waits for LDS.
 template <typename TM>
 __device__ __forceinline__ void sg_leg_solve(SmemS& s, const double* __restrict__ ws, const LegSys<double>& L, const double (&rhs)[3], double (&x)[3],
                                              const bool leg, const int N, const int tid) {
+  const double d = s.delta, th = s.theta, gp = th * d * d, gq = d;
+  const int kq = min(tid, 4 * N - 1) >> 2, lq = tid & 3;
   double a[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) a[c] = L.dinv[c] * rhs[c];
-  double b[6];
+  {
+    double b[6];
 #pragma unroll
-  for (int q = 0; q < 6; ++q) b[q] = quad_sum(fma(L.A[2][q], a[2], fma(L.A[1][q], a[1], L.A[0][q] * a[0])));
-  if (leg && (tid & 3) == 0) {
+    for (int q = 0; q < 6; ++q) b[q] = quad_sum(fma(L.A[2][q], a[2], fma(L.A[1][q], a[1], L.A[0][q] * a[0])));
+    if (leg) {
+      if (lq == 0) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) s.bq[6 * (tid >> 2) + q] = b[q];
+        for (int q = 0; q < 6; ++q) s.bq[6 * kq + q] = b[q];
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {   // rows 3 lq .. 3 lq + 2 of PG_k b_k  (row i = 6 h + c  ->  chain slot 2 c + h)
+        const int i = 3 * lq + t, h = i >= 6 ? 1 : 0, c = i - 6 * h;
+        const double* pg = s.PGs + 72 * kq + 6 * i;
+        double v = pg[0] * b[0];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) v = fma(pg[q], b[q], v);
+        s.s0[12 * kq + 2 * c + h] = v;
+      }
+    }
+    if (tid < 12) { s.pist[12 * N + tid] = 0.0; s.zst[tid] = 0.0; }
+    if constexpr (sizeof(TM) == 8) {   // fp64 chains: Lrow of all stages -> LDS
+      double* fb = reinterpret_cast<double*>(s.fbuf);
+      for (int e = tid; e < 128 * N; e += SG_NT) fb[e] = ws[(size_t)(e >> 7) * SG_WS_STAGE + (e & 127)];
+    }
   }
   __syncthreads();
-  sg_solve<TM>(s, ws, N, tid);
-  const double* yj = s.yq + 6 * (min(tid, 4 * N - 1) >> 2);
+  const TM* const frow = reinterpret_cast<const TM*>(s.fbuf);
+  const TM* const fcol = reinterpret_cast<const TM*>(s.fbuf) + (sizeof(TM) == 4 ? SG_NS * 128 : 0);
+  if (tid < 64) {   // backward chain: group 0 of wave 0 (the other groups of the wave run along on the same data)
+    const int c = tid & 7;
+    const TM msk = c < 6 ? (TM)1 : (TM)0;
+    TM pp = 0, pq = 0;
+    TM Lr[16];
+    {
+      const TM* f = frow + 128 * (N - 1) + 16 * c;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    double sum = L.A[c][0] * yj[0];
+      for (int t = 0; t < 16; ++t) Lr[t] = f[t];
+    }
+    double2 sn = *reinterpret_cast<const double2*>(s.s0 + 12 * (N - 1) + 2 * c);
+#pragma unroll 1
+    for (int k = N - 1; k >= 1; --k) {
+      TM Ln[16];
+      {
+        const TM* f = frow + 128 * (k - 1) + 16 * c;   // (stage 0's are loaded and not used)
 #pragma unroll
-    for (int q = 1; q < 6; ++q) sum = fma(L.A[c][q], yj[q], sum);
-    x[c] = a[c] - L.dinv[c] * sum;
+        for (int t = 0; t < 16; ++t) Ln[t] = f[t];
+      }
+      const double2 sn2 = *reinterpret_cast<const double2*>(s.s0 + 12 * (k - 1) + 2 * c);
+      TM sp = fma(msk, (TM)sn.x, pp), sq = fma(msk, (TM)sn.y, pq);
+      const TM cc = (TM)gp * sp + (TM)gq * sq;
+      TM g[8];
+      xor_gather8(cc, g);
+      TM a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { a0 = fma(Lr[t], g[t], a0); a1 = fma(Lr[4 + t], g[4 + t], a1); b0 = fma(Lr[8 + t], g[t], b0); b1 = fma(Lr[12 + t], g[4 + t], b1); }
+      sp -= a0 + a1; sq -= b0 + b1;
+      pp = sp; pq = fma((TM)d, sp, sq);
+      if (tid < 6) *reinterpret_cast<double2*>(s.pist + 12 * k + 2 * c) = make_double2((double)pp, (double)pq);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) Lr[t] = Ln[t];
+      sn = sn2;
+    }
+  }
+  __syncthreads();
+  // d_k = b_k - E_k Gam' pi_{k+1} -> P slots of s0  (fp64 chains: Lcol of all stages -> LDS; the backward chain is done with Lrow)
+  if constexpr (sizeof(TM) == 8) {
+    double* fb = reinterpret_cast<double*>(s.fbuf);
+    for (int e = tid; e < 128 * N; e += SG_NT) fb[e] = ws[(size_t)(e >> 7) * SG_WS_STAGE + 128 + (e & 127)];
+  }
+  for (int e = tid; e < 6 * N; e += SG_NT) {
+    const int k = e / 6, c = e - 6 * k;
+    const double* Ek = s.Es + 36 * k + 6 * c;
+    const double* pk = s.pist + 12 * (k + 1);
+    double acc = s.bq[e];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) acc -= Ek[q] * (gp * pk[2 * q] + gq * pk[2 * q + 1]);
+    s.s0[12 * k + 2 * c] = acc;
+  }
+  __syncthreads();
+  if (tid < 64) {   // forward chain
+    const int c = tid & 7;
+    const TM msk = c < 6 ? (TM)1 : (TM)0;
+    TM zp = 0, zq = 0;
+    TM Lc[16];
+    {
+      const TM* f = fcol + 16 * c;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) Lc[t] = f[t];
+    }
+    double dn = s.s0[2 * c];
+#pragma unroll 1
+    for (int k = 0; k < N; ++k) {
+      TM Ln[16];
+      {
+        const TM* f = fcol + 128 * min(k + 1, N - 1) + 16 * c;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) Ln[t] = f[t];
+      }
+      const double dn2 = s.s0[12 * min(k + 1, N - 1) + 2 * c];
+      const TM dk = msk * (TM)dn;
+      const TM tp = zp + (TM)d * zq + (TM)gp * dk, tq = zq + (TM)gq * dk;
+      TM g0[8], g1[8];
+      xor_gather8(tp, g0);
+      xor_gather8(tq, g1);
+      TM a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { a0 = fma(Lc[t], g0[t], a0); a1 = fma(Lc[4 + t], g0[4 + t], a1); b0 = fma(Lc[8 + t], g1[t], b0); b1 = fma(Lc[12 + t], g1[4 + t], b1); }
+      const TM o = (a0 + a1) + (b0 + b1);
+      zp = tp - (TM)gp * o; zq = tq - (TM)gq * o;
+      if (tid < 6) *reinterpret_cast<double2*>(s.zst + 12 * (k + 1) + 2 * c) = make_double2((double)zp, (double)zq);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) Lc[t] = Ln[t];
+      dn = dn2;
+    }
+  }
+  __syncthreads();
+  {   // y_k = PG_k' z_{k+1} + Gam' pi_{k+1}: lanes 0..2 of the quad take two components each, DPP hands them round
+    const double* zk = s.zst + 12 * (kq + 1);
+    const double* pk = s.pist + 12 * (kq + 1);
+    const int c0 = 2 * min(lq, 2);
+    double y0 = gp * pk[2 * c0] + gq * pk[2 * c0 + 1], y1 = gp * pk[2 * c0 + 2] + gq * pk[2 * c0 + 3];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {   // PG row i = 6 h + c multiplies z slot 2 c + h
+      const int h = i >= 6 ? 1 : 0, c = i - 6 * h;
+      const double zv = zk[2 * c + h];
+      y0 = fma(s.PGs[72 * kq + 6 * i + c0], zv, y0);
+      y1 = fma(s.PGs[72 * kq + 6 * i + c0 + 1], zv, y1);
+    }
+    const double yj[6] = {dpp_mov<0x00>(y0), dpp_mov<0x00>(y1), dpp_mov<0x55>(y0), dpp_mov<0x55>(y1), dpp_mov<0xAA>(y0), dpp_mov<0xAA>(y1)};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double sum = L.A[c][0] * yj[0];
+#pragma unroll
+      for (int q = 1; q < 6; ++q) sum = fma(L.A[c][q], yj[q], sum);
+      x[c] = a[c] - L.dinv[c] * sum;
+    }
   }
 }
 
@@ -543,7 +553,7 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
   for (;;) {
     LegSys<double> Ls;
     sg_admm_sys(s, cfg, Lg, (double)rho, Ls);
-    sg_build_E(Ls, ws, Lg.leg, tid);
+    sg_build_E(s, Ls, Lg.leg, tid);
     sg_factor<TM>(s, ws, N, tid);
     const double sigma = cfg.sigma, relax = cfg.relax, om = 1.0 - relax, BIG = 1e30, r = (double)rho, mu = s.mu;
     double u[3], z[5], yh[5];
@@ -624,7 +634,7 @@ __device__ __forceinline__ int sg_polish_round(SmemS& s, const DevCfg& cfg, SLeg
     const ActSet as(code, Lg.stance);
     LegSys<double> Ls;
     sg_polish_sys(s, Lg, as, Ls);
-    sg_build_E(Ls, ws, Lg.leg, tid);
+    sg_build_E(s, Ls, Lg.leg, tid);
     sg_factor<double>(s, ws, N, tid);
     const int zs = as.zs, xs = as.xs, ys = as.ys;
     const bool ez = as.ez, ex = as.ex, ey = as.ey;
@@ -731,6 +741,7 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
     int bad = 0;
     double* const xd = s.pist;   // x_des staging [N+1][13] over pist | zst (contiguous members)
     static_assert(offsetof(SmemS, zst) == offsetof(SmemS, pist) + sizeof(double) * (SG_NS + 1) * 12, "x_des staging spans pist | zst");
+  static_assert(sizeof(SmemS) <= 160 * 1024, "LDS of a CU");
     for (int i = tid; i < NX; i += SG_NT) { const double v = (double)in.xdes[(size_t)b * NX + i]; xd[i] = v; bad |= !isfinite(v); }
     if (tid < 13) { const double v = (double)in.x0[(size_t)b * 13 + tid]; s.x0[tid] = v; bad |= !isfinite(v); }
     if (tid == 0) { const double v = (double)in.mu[b]; s.mu = v; bad |= !isfinite(v); }

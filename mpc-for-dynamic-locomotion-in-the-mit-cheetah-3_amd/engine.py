@@ -107,23 +107,25 @@ class MPCBatch:
                 "feet_id": torch.as_tensor(np.ascontiguousarray(g["feet_id"], dtype=np.uint8)).to(self.device).contiguous()}
 
     def solve_batch_gait(self, x0, ref, feet0, footholds, gait, feet_id, mu, want_X=False, stream=None, u_init=None):
-        """Gait entry point: contact masks, stance lever arms and x_des are generated on the device (include/mpcqp.h)."""
+        """Gait entry point: contact masks, stance lever arms and x_des are generated on the device (include/mpcqp.h) from S plan steps
+        per robot (footholds [B,S,4,3], feet_id [B,S,4]; S = 2 is the original two-step form)."""
         torch = _torch()
         N = self.N
         B = int(x0.shape[0])
+        S = int(footholds.shape[1]) if footholds.dim() == 4 else -1
         for t, shape, dt in ((x0, (B, 13), self.tdtype), (ref, (B, 10), self.tdtype), (feet0, (B, 4, 3), self.tdtype),
-                             (footholds, (B, 2, 4, 3), self.tdtype), (gait, (B, 4), torch.int32), (feet_id, (B, 2, 4), torch.uint8),
+                             (footholds, (B, S, 4, 3), self.tdtype), (gait, (B, 4), torch.int32), (feet_id, (B, S, 4), torch.uint8),
                              (mu, (B,), self.tdtype)):
-            if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+            if S < 1 or tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != self.device:
                 raise ValueError(f"operand mismatch: expected {shape} {dt} contiguous on {self.device}, got "
                                  f"{tuple(t.shape)} {t.dtype} on {t.device}")
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         out = self._outputs(B, want_X, st)
         self._seed(out, u_init, st)
-        self.engine.solve_batch_gait_ptr(B, x0.data_ptr(), ref.data_ptr(), feet0.data_ptr(), footholds.data_ptr(), gait.data_ptr(),
-                                         feet_id.data_ptr(), mu.data_ptr(), out["u"].data_ptr(),
-                                         out["X"].data_ptr() if want_X else None, out["status"].data_ptr(),
-                                         out["iters"].data_ptr(), out["res"].data_ptr(), st.cuda_stream)
+        self.engine.solve_batch_gait_steps_ptr(B, S, x0.data_ptr(), ref.data_ptr(), feet0.data_ptr(), footholds.data_ptr(), gait.data_ptr(),
+                                               feet_id.data_ptr(), mu.data_ptr(), out["u"].data_ptr(),
+                                               out["X"].data_ptr() if want_X else None, out["status"].data_ptr(),
+                                               out["iters"].data_ptr(), out["res"].data_ptr(), st.cuda_stream)
         return out
 
     def rollout(self, x, ref, plan_pos, plan_feet_id, plan_meta, tick, mu, T, log=True, stream=None):

@@ -122,9 +122,10 @@ def config5(B=4096, dtype=np.float64):
 # Compact gait descriptors (include/mpcqp.h, mpcqp_solve_batch_gait) and their host expansion
 # ----------------------------------------------------------------------------------------------------------------------
 def make_gait_batch(B, N=10, delta=0.03, seed=20250812, gait_names=("trot", "pronk", "amble", "gallop"), mus=(0.3, 0.5, 0.7, 1.0),
-                    stride=0.06):
+                    stride=0.06, steps=2):
     """Same state distribution as `make_batch`, but described the way the controller knows it: measured feet, the
-    planned footholds of the current and next step (swing feet land `stride` ahead along the heading), the gait clock."""
+    planned footholds of the current and the following `steps - 1` steps (swing feet land `stride` ahead along the heading, the
+    gait alternates feet_id with its complement step by step, src/footstep_planner.py:159-177), the gait clock."""
     rng = np.random.default_rng(seed)
     base = make_batch(B, N, delta, seed, gait_names, mus)
     x0 = base["x0"]
@@ -139,19 +140,22 @@ def make_gait_batch(B, N=10, delta=0.03, seed=20250812, gait_names=("trot", "pro
     t0 = base["t0"]
     step_par = (t0 // (SS_TICKS + DS_TICKS)) % 2
     fid_cur = np.where(step_par[:, None] == 0, fid0, 1 - fid0).astype(np.uint8)
-    feet_id = np.stack([fid_cur, 1 - fid_cur], axis=1).astype(np.uint8)
     heading = np.stack([c, s, np.zeros(B)], axis=1)
-    fh0 = feet0 + rng.normal(0.0, 0.003, (B, 4, 3)) * np.array([1.0, 1.0, 0.0])
-    fh1 = np.where(fid_cur[:, :, None] == 0, fh0 + stride * heading[:, None, :], fh0)   # feet swinging now land ahead
+    fids = [fid_cur]
+    fhs = [feet0 + rng.normal(0.0, 0.003, (B, 4, 3)) * np.array([1.0, 1.0, 0.0])]
+    for _ in range(1, steps):
+        fhs.append(np.where(fids[-1][:, :, None] == 0, fhs[-1] + stride * heading[:, None, :], fhs[-1]))   # feet swinging now land ahead
+        fids.append((1 - fids[-1]).astype(np.uint8))
     gait = np.stack([t0 % (SS_TICKS + DS_TICKS), np.full(B, SS_TICKS), np.full(B, DS_TICKS), np.zeros(B, int)], axis=1).astype(np.int32)
-    return {"x0": x0, "ref": ref, "feet0": feet0, "footholds": np.stack([fh0, fh1], axis=1), "gait": gait, "feet_id": feet_id,
+    return {"x0": x0, "ref": ref, "feet0": feet0, "footholds": np.stack(fhs, axis=1), "gait": gait, "feet_id": np.stack(fids, axis=1).astype(np.uint8),
             "mu": base["mu"]}
 
 
 def expand_gait_batch(g, N=10, delta=0.03):
-    """numpy expansion of the descriptors into the operator tuple (the host loop of src/mpc.py:178-254, vectorised)."""
+    """numpy expansion of the descriptors into the operator tuple (the host loop of src/mpc.py:178-254, vectorised): stage k lies in
+    step min((t_in_step + k) / (ss + ds), S - 1) of the S described steps (include/mpcqp.h)."""
     x0, ref = np.asarray(g["x0"], float), np.asarray(g["ref"], float)
-    B = len(x0)
+    B, S = len(x0), np.asarray(g["footholds"]).shape[1]
     k = np.arange(N + 1)[None, :, None]
     xdes = np.zeros((B, N + 1, 13))
     xdes[:, :, 0], xdes[:, :, 1] = ref[:, None, 0], ref[:, None, 1]
@@ -162,7 +166,7 @@ def expand_gait_batch(g, N=10, delta=0.03):
     xdes[:, :, 12] = x0[:, None, 12]
     tis, ss, ds = (np.asarray(g["gait"])[:, i][:, None] for i in range(3))
     tau = tis + np.arange(N)[None, :]
-    st = (tau >= ss + ds).astype(int)
+    st = np.minimum(tau // (ss + ds), S - 1)
     tau = tau - st * (ss + ds)
     fid = np.asarray(g["feet_id"])[np.arange(B)[:, None], st]                     # [B,N,4]
     contact = np.where((tau < ss)[:, :, None], fid, 1).astype(np.uint8)

@@ -634,12 +634,12 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0v, const void* rv
 
 /* Gait entry: expand the compact descriptors on the host exactly as MPC.solve does (src/mpc.py:178-254, planner queries
  * src/footstep_planner.py:226-246), then solve as above.  Literal loops; shares nothing with the device expansion. */
-int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0v, const void* refv, const void* feet0v,
-                           const void* footholdsv, const int32_t* gait, const uint8_t* feet_id, const void* muv, void* uv,
-                           void* Xv, int32_t* status, int32_t* iters, float* res, void* stream) {
+int mpcqp_solve_batch_gait_steps(mpcqp_handle h, int64_t B, int32_t S, const void* x0v, const void* refv, const void* feet0v,
+                                 const void* footholdsv, const int32_t* gait, const uint8_t* feet_id, const void* muv, void* uv,
+                                 void* Xv, int32_t* status, int32_t* iters, float* res, void* stream) {
   if (!h) return MPCQP_EINVAL;
-  if (B < 0 || (B > 0 && (!x0v || !refv || !feet0v || !footholdsv || !gait || !feet_id || !muv || !uv || !status || !iters))) {
-    snprintf(h->err, sizeof(h->err), "mpcqp_solve_batch_gait: null buffer or negative batch");
+  if (B < 0 || S < 1 || (B > 0 && (!x0v || !refv || !feet0v || !footholdsv || !gait || !feet_id || !muv || !uv || !status || !iters))) {
+    snprintf(h->err, sizeof(h->err), "mpcqp_solve_batch_gait: null buffer, negative batch or no plan step");
     return MPCQP_EINVAL;
   }
   const int N = h->cfg.N;
@@ -651,8 +651,8 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0v, const voi
   if (!r || !xd || !ct) { free(r); free(xd); free(ct); return MPCQP_ENOMEM; }
   for (int64_t b = 0; b < B; b++) {
     const double* rf = ref + b * 10;
-    const int tis = gait[b * 4 + 0], ss = gait[b * 4 + 1], ds = gait[b * 4 + 2];
-    if (N > ss + ds) { free(r); free(xd); free(ct); snprintf(h->err, sizeof(h->err), "gait: N must not exceed ss + ds"); return MPCQP_EINVAL; }
+    const int tis = gait[b * 4 + 0] < 0 ? 0 : gait[b * 4 + 0], ss = gait[b * 4 + 1] < 0 ? 0 : gait[b * 4 + 1];
+    const int per = (ss + (gait[b * 4 + 2] < 0 ? 0 : gait[b * 4 + 2])) < 1 ? 1 : ss + (gait[b * 4 + 2] < 0 ? 0 : gait[b * 4 + 2]);
     for (int k = 0; k <= N; k++) { /* src/mpc.py:202-214 */
       double* xk = xd + (b * (N + 1) + k) * NX;
       memset(xk, 0, sizeof(double) * NX);
@@ -663,19 +663,26 @@ int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0v, const voi
       xk[12] = x0[b * NX + 12];
     }
     for (int k = 0; k < N; k++) {
-      int tau = tis + k, st = 0;
-      if (tau >= ss + ds) { tau -= ss + ds; st = 1; }
+      const int tau = tis + k;
+      int st = tau / per; if (st > S - 1) st = S - 1;      /* past the descriptor's last step: that step, its time keeps running */
+      const int tin = tau - st * per;                      /* (footstep_planner.py:226-237 clamps the same way) */
       for (int l = 0; l < 4; l++) {
-        ct[(b * N + k) * 4 + l] = (tau < ss) ? (feet_id[b * 8 + st * 4 + l] ? 1 : 0) : 1;       /* footstep_planner.py:239-246 */
+        ct[(b * N + k) * 4 + l] = (tin < ss) ? (feet_id[((size_t)b * S + st) * 4 + l] ? 1 : 0) : 1;   /* footstep_planner.py:239-246 */
         for (int a = 0; a < 3; a++)                                                           /* src/mpc.py:218-239 */
           r[((b * N + k) * 4 + l) * 3 + a] = k == 0 ? feet0[b * 12 + l * 3 + a] - x0[b * NX + 3 + a]
-                                                    : fh[b * 24 + st * 12 + l * 3 + a] - xd[(b * (N + 1) + k) * NX + 3 + a];
+                                                    : fh[(((size_t)b * S + st) * 4 + l) * 3 + a] - xd[(b * (N + 1) + k) * NX + 3 + a];
       }
     }
   }
   const int rc = mpcqp_solve_batch(h, B, x0v, r, ct, xd, muv, uv, Xv, status, iters, res, stream);
   free(r); free(xd); free(ct);
   return rc;
+}
+
+int mpcqp_solve_batch_gait(mpcqp_handle h, int64_t B, const void* x0v, const void* refv, const void* feet0v,
+                           const void* footholdsv, const int32_t* gait, const uint8_t* feet_id, const void* muv, void* uv,
+                           void* Xv, int32_t* status, int32_t* iters, float* res, void* stream) {
+  return mpcqp_solve_batch_gait_steps(h, B, 2, x0v, refv, feet0v, footholdsv, gait, feet_id, muv, uv, Xv, status, iters, res, stream);
 }
 
 /* Closed-loop roll-out on host memory, fp64: the literal per-tick loop of Lite3Controller.customPreStep / MPC.solve

@@ -30,10 +30,12 @@ def pytest_configure(config):
             have = False
         if have:
             env = dict(os.environ, MPCQP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-            _BENCH2["proc"] = subprocess.Popen(
-                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                 "--master-port", "29517", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--allgather",
-                 "--no-cpu-baseline", "--no-breakdown"], cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+            # weak mode (4096 QPs per rank, one draw per rank), then strong mode (one batch of 6001 QPs in contiguous, ragged shards):
+            # both in ONE child shell, one after the other (at most two ranks of the rehearsal on the card at a time)
+            run2 = (f"{sys.executable} -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port %d "
+                    f"{os.path.join(REPO, 'bench.py')} --gpus 2 --steps 3 --warmup 1 --allgather --no-cpu-baseline --no-breakdown %s")
+            _BENCH2["proc"] = subprocess.Popen(["bash", "-c", (run2 % (29517, "")) + " && " + (run2 % (29519, "--global-batch 6001"))],
+                                               cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
             # ... and the RCCL ("nccl") branch of the same script with a single rank: process group on the device, barrier,
             # all-reduce and all-gather of device tensors -- every collective call the 8-GPU run makes.
             env1 = dict(os.environ, MPCQP_BENCH_BACKEND="nccl", MPCQP_BENCH_DIST1="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")

@@ -142,17 +142,26 @@ def test_horizon20_warm_start_same_optimum(oracle_solve):
 
 
 def test_two_rank_bench_rehearsal():
-    """bench.py --gpus 2 (gloo, both ranks on this one GPU), launched as a fresh child before this process initialised HIP."""
+    """bench.py --gpus 2 (gloo, both ranks on this one GPU), launched as a fresh child before this process initialised HIP: the weak
+    mode the driver's scaling runs use (4096 QPs per rank, one draw per rank) and the strong mode of BASELINE configs[3]
+    (--global-batch: one batch in contiguous shards, here ragged: 3001 + 3000)."""
     rc, stdout, stderr = bench2_result()
     assert rc == 0, stderr[-2000:]
     lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, stdout[-2000:]
+    assert len(lines) == 2, stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak" and j["unit"] == "QP solves/s"
-    assert j["config"]["allgather"] is True and j["config"]["batch_per_gpu"] == 4096
-    # whole-job value = units all ranks processed / max-over-ranks time
+    assert j["config"]["allgather"] is True and j["config"]["batch_per_gpu"] == 4096 and j["config"]["global_batch"] == 8192
+    assert "one draw per rank" in j["config"]["shards"]
+    # whole-job value = units all ranks processed / max-over-ranks time; the per-rank times are reported next to it
     assert abs(j["value"] - 2 * 4096 * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]
-    assert j["config"]["solved_fraction"] >= 0.99 and "roofline" in j and "cpu_baseline" not in j
+    rk = j["rank_kernel_ms"]
+    assert len(rk["per_rank"]) == 2 and rk["min"] <= rk["mean"] <= rk["max"] and rk["max"] == j["roofline"]["kernel_ms"]
+    assert j["config"]["solved_fraction"] >= 0.999 and "roofline" in j and "cpu_baseline" not in j
+    k = json.loads(lines[1])
+    assert k["n_gpus"] == 2 and k["scaling"] == "strong" and k["config"]["global_batch"] == 6001 and k["config"]["batch_per_gpu"] == 3001
+    assert abs(k["value"] - 6001 * 3 / (k["ms_per_step"] * 3e-3)) <= 1e-6 * k["value"]
+    assert k["config"]["solved_fraction"] >= 0.999 and len(k["rank_kernel_ms"]["per_rank"]) == 2
 
 
 def test_one_rank_rccl_bench_rehearsal():

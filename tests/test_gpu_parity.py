@@ -266,13 +266,52 @@ def test_gait_entry_point_device_side_generation(oracle_solve):
     torch.cuda.synchronize()
     ok3 = solved(o3["status"].cpu().numpy())
     assert ok3.mean() >= 0.97 and rel_err(o3["u"].cpu().numpy(), ref["u"])[ok3].max() <= 1e-4
-    # the entry point refuses configurations the fast path does not cover
-    s20 = mpcqp.MPCBatch(N=20)
-    e = sol32.upload_gait(mpcqp.synth.make_gait_batch(2))
-    with pytest.raises(mpcqp.MpcQpError):
-        s20.engine.solve_batch_gait_ptr(2, e["x0"].data_ptr(), e["ref"].data_ptr(), e["feet0"].data_ptr(), e["footholds"].data_ptr(),
-                                        e["gait"].data_ptr(), e["feet_id"].data_ptr(), e["mu"].data_ptr(), e["x0"].data_ptr(),
-                                        None, e["gait"].data_ptr(), e["gait"].data_ptr(), None)
+
+
+def test_gait_entry_point_any_horizon(oracle_solve):
+    """Round-2 review: the gait entry stopped at N = 10 and two plan steps.  mpcqp_solve_batch_gait_steps takes S steps per robot
+    and any horizon: BASELINE config 5 (N = 20: up to three 15-tick steps) through the descriptors == through the tuple == the
+    oracle; the two-step form at N = 20 clamps like the planner does at the end of a plan."""
+    N = 20
+    g = mpcqp.synth.make_gait_batch(384, N=N, steps=3, seed=20250811)
+    t = mpcqp.synth.expand_gait_batch(g, N=N)
+    ref = oracle_solve({k: v[:128] for k, v in t.items()}, N=N)
+    sol = mpcqp.MPCBatch(N=N, io_dtype="f64", precision="mixed")
+    dg = sol.upload_gait(g)
+    o = sol.solve_batch_gait(dg["x0"], dg["ref"], dg["feet0"], dg["footholds"], dg["gait"], dg["feet_id"], dg["mu"], want_X=True)
+    torch.cuda.synchronize()
+    ug, Xg, stg, itg = (o[k].cpu().numpy().copy() for k in ("u", "X", "status", "iters"))
+    dt = sol.upload(t)
+    o2 = sol.solve_batch(dt["x0"], dt["r"], dt["contact"], dt["xdes"], dt["mu"], want_X=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(stg, o2["status"].cpu().numpy()) and np.array_equal(itg, o2["iters"].cpu().numpy())
+    assert np.array_equal(ug, o2["u"].cpu().numpy())                  # the device expansion produces the host expansion's tuple: same bits
+    ok = solved(stg)
+    assert ok.mean() >= 0.99
+    assert rel_err(ug[:128], ref["u"])[ok[:128]].max() <= 1e-4 and np.abs(Xg[:128][ok[:128]] - ref["X"][ok[:128]]).max() <= 1e-4
+    # two described steps at N = 20: the third step's stages fall back to the second step, all feet down
+    g2 = mpcqp.synth.make_gait_batch(64, N=N, steps=2, seed=20250811)
+    t2 = mpcqp.synth.expand_gait_batch(g2, N=N)
+    d2 = sol.upload_gait(g2)
+    oa = sol.solve_batch_gait(d2["x0"], d2["ref"], d2["feet0"], d2["footholds"], d2["gait"], d2["feet_id"], d2["mu"])
+    torch.cuda.synchronize()
+    ua = oa["u"].cpu().numpy().copy()
+    dt2 = sol.upload(t2)
+    ob = sol.solve_batch(dt2["x0"], dt2["r"], dt2["contact"], dt2["xdes"], dt2["mu"])
+    torch.cuda.synchronize()
+    assert np.array_equal(ua, ob["u"].cpu().numpy())
+    # the reference's own horizon through the descriptors (N = 60: five 15-tick steps), against the tuple entry
+    g60 = mpcqp.synth.make_gait_batch(16, N=60, delta=0.01, steps=5, seed=3, gait_names=("trot", "gallop"), mus=(0.7, 1.0))
+    t60 = mpcqp.synth.expand_gait_batch(g60, N=60, delta=0.01)
+    s60 = mpcqp.MPCBatch(N=60, delta=0.01, io_dtype="f64", precision="mixed")
+    d60 = s60.upload_gait(g60)
+    oc = s60.solve_batch_gait(d60["x0"], d60["ref"], d60["feet0"], d60["footholds"], d60["gait"], d60["feet_id"], d60["mu"])
+    torch.cuda.synchronize()
+    uc, sc = oc["u"].cpu().numpy().copy(), oc["status"].cpu().numpy().copy()
+    dt60 = s60.upload(t60)
+    od = s60.solve_batch(dt60["x0"], dt60["r"], dt60["contact"], dt60["xdes"], dt60["mu"])
+    torch.cuda.synchronize()
+    assert np.array_equal(uc, od["u"].cpu().numpy()) and solved(sc).mean() >= 0.9
 
 
 @pytest.mark.parametrize("general", [False, True])

@@ -170,20 +170,29 @@ def test_nonfinite_input_flagged(oracle_solve):
 
 def test_gait_descriptor_expansion_host_vs_oracle(oracle_lib):
     """The gait entry point of the checker (literal C loops) and the vectorised numpy expansion agree exactly, and the
-    expansion reproduces the planner semantics (phase = feet_id during the first ss ticks of a step, else all stance)."""
-    g = mpcqp.synth.make_gait_batch(32)
-    t = mpcqp.synth.expand_gait_batch(g)
-    eng = mpcqp.Engine(oracle_lib, oracle_lib.default_config(max_iter=4000))
-    a = eng.solve_batch_gait_host(g)
-    b = eng.solve_batch_host(t["x0"], t["r"], t["contact"], t["xdes"], t["mu"])
-    assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["X"], b["X"]) and np.array_equal(a["status"], b["status"])
-    for i in range(32):
-        tis, ss, ds = g["gait"][i][:3]
-        for k in range(10):
-            tau = tis + k
-            st = int(tau >= ss + ds); tau -= st * (ss + ds)
-            want = g["feet_id"][i, st] if tau < ss else np.ones(4, np.uint8)
-            assert np.array_equal(t["contact"][i, k], want)
+    expansion reproduces the planner semantics (phase = feet_id during the first ss ticks of a step, else all stance) --
+    two described steps at N = 10, three and four at N = 20 (a horizon of 20 ticks spans up to three 15-tick steps), and a
+    descriptor that is too short for its horizon (the last step's time runs on: all stance, the planner's own clamp)."""
+    for N, S in ((10, 2), (20, 3), (20, 4), (20, 1)):
+        g = mpcqp.synth.make_gait_batch(24, N=N, steps=S)
+        t = mpcqp.synth.expand_gait_batch(g, N=N)
+        eng = mpcqp.Engine(oracle_lib, oracle_lib.default_config(N=N, max_iter=4000))
+        a = eng.solve_batch_gait_host(g)
+        b = eng.solve_batch_host(t["x0"], t["r"], t["contact"], t["xdes"], t["mu"])
+        assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["X"], b["X"]) and np.array_equal(a["status"], b["status"])
+        for i in range(24):
+            tis, ss, ds = g["gait"][i][:3]
+            for k in range(N):
+                tau = tis + k
+                st = min(tau // (ss + ds), S - 1); tau -= st * (ss + ds)
+                want = g["feet_id"][i, st] if tau < ss else np.ones(4, np.uint8)
+                assert np.array_equal(t["contact"][i, k], want)
+                if k > 0:
+                    assert np.allclose(t["r"][i, k], g["footholds"][i, st] - t["xdes"][i, k, 3:6], atol=0)
+    # with enough steps the schedule is the alternating one of the tuple generator (src/footstep_planner.py:159-177)
+    g3 = mpcqp.synth.make_gait_batch(64, N=20, steps=3)
+    base = mpcqp.synth.make_batch(64, 20, 0.03, 20250812, ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0))
+    assert np.array_equal(mpcqp.synth.expand_gait_batch(g3, N=20)["contact"], base["contact"])
 
 
 def test_torque_map_matches_reference_expression(oracle_lib):

@@ -51,4 +51,19 @@ if "rate" in which:
         b = mpcqp.synth.make_batch(B, 60, 0.01, 11, ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0))
         for prec in ("mixed", "f64"):
             o = gpu(b, 60, 0.01, prec, mpcqp.FLAG_POLISH)
-            print(f"N=60 B={B} {prec}: {o['ms']:.1f} ms = {B / o['ms']:.1f} k QP/s, solved {np.mean(o['status'] == 1):.3f}, iters mean {np.mean(o['iters'] % 1000):.0f} polish {np.mean(o['iters'] // 1000):.1f}", flush=True)
+            it = o["iters"] % 1000 + 0; ps = o["iters"] // 1000
+            print(f"N=60 B={B} {prec}: {o['ms']:.1f} ms = {B / o['ms']:.1f} k QP/s, solved {np.mean(o['status'] == 1):.3f}, iters mean {np.mean(it):.0f} max {it.max()} hist(/100) {np.bincount(it // 100).tolist()} "
+                  f"polish mean {np.mean(ps):.1f} max {ps.max()}; unsolved: {[(int(i), int(o['iters'][i]), float(b['mu'][i]), int(b['gait_ids'][i])) for i in np.where(o['status'] != 1)[0][:6]]}", flush=True)
+if "prof" in which:
+    q = np.load(os.path.join(REPO, "tests", "golden", "qp_inputs.npz"))
+    for N in (10, 20, 60):
+        b = {"x0": q[f"N{N}_x0"], "r": q[f"N{N}_r"], "contact": q[f"N{N}_contact"], "xdes": q[f"N{N}_xdes"], "mu": np.full(len(q["ticks"]), float(q["mu"]))}
+        for prec in ("mixed", "f64"):
+            ms = {}
+            for K in (50, 100, 200):
+                o = gpu(b, N, float(q["delta"]), prec, mpcqp.FLAG_STAGE_KERNEL, max_iter=K, check_every=K, eps_abs=0.0, eps_rel=0.0)
+                ms[K] = o["ms"]
+            per_it = (ms[200] - ms[100]) / 100 * 1e3
+            print(f"N={N} {prec} ADMM only: K=50/100/200 -> {ms[50]:.3f} / {ms[100]:.3f} / {ms[200]:.3f} ms; {per_it:.2f} us per iteration, fixed part {ms[100] - 0.1 * per_it:.3f} ms", flush=True)
+            o = gpu(b, N, float(q["delta"]), prec, mpcqp.FLAG_POLISH | mpcqp.FLAG_STAGE_KERNEL, max_iter=25, check_every=25, polish_max=1)
+            print(f"      25 iterations + 1 polish step: {o['ms']:.3f} ms (status {o['status'][:4].tolist()}, iters {o['iters'][:4].tolist()})", flush=True)
