@@ -142,6 +142,47 @@ def gait_breakdown(solver, N, delta, B, steps=5, precision="mixed"):
     torch.cuda.synchronize()
     st = o["status"].cpu().numpy()
     out["mixed_batch_65536"] = {"qp_per_s": big * 3 / (e0.elapsed_time(e1) * 1e-3), "solved_fraction": float(((st == 1) | (st == 2)).mean())}
+    # the reference's arithmetic is all-fp64: the same workload with every tile, vector and residual in fp64
+    try:
+        s64 = mpcqp.MPCBatch(N=N, delta=delta, device=solver.device.index, io_dtype="f32", precision="f64", flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)
+        b = mpcqp.synth.make_batch(B, N, delta, 20250809, allg, (0.3, 0.5, 0.7, 1.0))
+        dev = s64.upload(b)
+        for _ in range(2):
+            o = s64.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            o = s64.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+        e1.record()
+        torch.cuda.synchronize()
+        st = o["status"].cpu().numpy()
+        out["f64_b4096"] = {"qp_per_s": B * steps / (e0.elapsed_time(e1) * 1e-3), "solved_fraction": float(((st == 1) | (st == 2)).mean()),
+                            "note": "all-fp64 arithmetic (MPCQP_PREC_F64), same batch as `value`"}
+        del s64
+    except Exception as e:
+        out["f64_b4096"] = {"error": repr(e)}
+    # the reference's OWN configuration (N = 60, delta = 0.01, src/main.py:37,41) on the stage-wise engine: secondary, a different
+    # horizon than the metric's -- the reference's figure for this setting is 61 solves/s on its CPU
+    try:
+        Bn = 1024
+        s60 = mpcqp.MPCBatch(N=60, delta=0.01, device=solver.device.index, io_dtype="f32", precision=precision, flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)
+        b = mpcqp.synth.make_batch(Bn, 60, 0.01, 20250809, allg, (0.3, 0.5, 0.7, 1.0))
+        dev = s60.upload(b)
+        o = s60.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2):
+            o = s60.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+        e1.record()
+        torch.cuda.synchronize()
+        st = o["status"].cpu().numpy()
+        out["reference_horizon_n60_b1024"] = {"qp_per_s": Bn * 2 / (e0.elapsed_time(e1) * 1e-3), "solved_fraction": float(((st == 1) | (st == 2)).mean()),
+                                              "note": "N = 60, delta = 0.01, mixed gaits + mu sweep, stage-wise engine (csrc/mpcqp_stage.h)"}
+        del s60
+    except Exception as e:
+        out["reference_horizon_n60_b1024"] = {"error": repr(e)}
     # two independent batches of B in flight: two handles on two HIP streams (a handle serves one stream at a time,
     # include/mpcqp.h).  The tail of one launch is filled by the head of the other -- what a caller with more than one fleet gets per
     # batch of B.  NOT `value`: that is one batch per step on one stream.

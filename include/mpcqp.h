@@ -97,8 +97,8 @@ typedef struct MpcQpConfig {
   double Ibody_inv[3];  /* diag(1/0.24, 1, 1) (src/mpc.py:73-76) */
   double w[13];         /* state weights (src/mpc.py:122-134) */
   double alpha;         /* force weight; 0.0 in the reference (src/mpc.py:121).  Below 1e-2 the engine solves at 1e-2 and walks the
-                           weight down by continuation; 0.0 ends at 3e-6 (objective / states / net wrench of the alpha = 0 optimum
-                           to 1e-6 / 1e-4 / 1e-4; the forces themselves are not unique at 0) */
+                           weight down by continuation; 0.0 ends at 3e-6 (2e-5 on the stage-wise engine: objective / states / net
+                           wrench of the alpha = 0 optimum to 1e-6 / 1e-4 / 1e-4; the forces themselves are not unique at 0) */
   double f_min, f_max;  /* 3, 100 (src/mpc.py:45-46) */
   int32_t disc;         /* MPCQP_DISC_* */
   int32_t dtype;        /* MPCQP_DTYPE_* of the caller's buffers */
@@ -123,10 +123,12 @@ typedef struct MpcQpConfig {
   int32_t listed_max;   /* device-fills up to which an ordered launch is one workgroup per QP (beyond: resident workgroups on a queue);
                            0: 4; -1: always queued */
   float adapt_thr;      /* residual ratio at the early rho check beyond which a QP gets a larger penalty and a longer block; 0: per precision */
-  double alpha_floor;   /* where the regulariser continuation of an alpha = 0 request ends; 0: 3e-6 */
+  double alpha_floor;   /* where the regulariser continuation of an alpha = 0 request ends; 0: 3e-6 (stage-wise engine: 2e-5) */
   int32_t polish_patience; /* polish steps of a round that may fail to halve the KKT violation before the round gives up; 0: default */
-  int32_t polish_cheap_steps; /* ... and the further steps a round may take beyond that as long as each only UPDATES S^-1 (few changed
-                                 leg-stages); 0: default, -1: none */
+  int32_t polish_cheap_steps; /* ... and the further steps a round may take beyond that as long as each only UPDATES S^-1 on at most
+                                 polish_cheap_legs changed leg-stages; 0: default, -1: none */
+  int32_t polish_cheap_legs;  /* 0: default */
+  int32_t reserved0;
 } MpcQpConfig;
 
 typedef struct mpcqp_engine* mpcqp_handle;

@@ -48,6 +48,7 @@ struct DevCfg {
   float adapt_thr;      // wrench engine: residual ratio at the early rho check beyond which a QP gets a larger penalty and a longer block
   int patience;         // wrench engine: polish steps of a round that may fail to halve the KKT violation before the round gives up
   int cheap_steps;      // wrench engine: ... and the steps a round may go on beyond that while they only update the inverse
+  int cheap_legs;       // wrench engine: ... on at most this many changed leg-stages
 };
 
 // Problem constants staged in LDS in the vector precision (keeps ~100 scalar registers free).

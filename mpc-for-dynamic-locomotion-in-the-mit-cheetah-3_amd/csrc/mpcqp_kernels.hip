@@ -541,6 +541,7 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   e->listed_max = cfg->listed_max > 0 ? cfg->listed_max : (cfg->listed_max < 0 ? 0 : 4);
   d.patience = cfg->polish_patience > 0 ? cfg->polish_patience : POLISH_PATIENCE;
   d.cheap_steps = cfg->polish_cheap_steps > 0 ? cfg->polish_cheap_steps : (cfg->polish_cheap_steps < 0 ? 0 : POLISH_CHEAP_STEPS);
+  d.cheap_legs = cfg->polish_cheap_legs > 0 ? cfg->polish_cheap_legs : POLISH_CHEAP_LEGS;
 
   // coefficient tables: c0[j][j'] = delta^2 (N - max(j,j')),
   // c1[j][j'] = delta^4 sum_{k > max(j,j')}^{N} (k-1-j+theta)(k-1-j'+theta)
@@ -563,6 +564,11 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   // Other horizons (the reference's committed N = 60, src/main.py:37) and MPCQP_FLAG_STAGE_KERNEL: the stage-wise engine.
   if (he == hipSuccess && (N != 10 && N != 20) && !e->form_ok) { delete[] tab; return reject(MPCQP_EINVAL); }
   if (he == hipSuccess && stage_path_applies(e)) {
+    // The recursion's solve carries ~10 x the error of the dense fp64 sweep (tools/stage_proto.py), and the Woodbury form amplifies it
+    // by 1 / (2 alpha): the alpha = 0 continuation of this engine ends at 2e-5 (objective within 2e-7, states within 9e-5 of the
+    // alpha = 0 optimum on the golden log ticks at N = 10 / 20 / 60; at 1e-5 the polish refinement stops contracting at N = 60,
+    // tools/stage_floor.py)
+    if (!(cfg->alpha_floor > 0)) e->dev.alpha_floor = SG_ALPHA_FLOOR;
     int per_cu = 0;
     const bool f64 = e->cfg.precision == MPCQP_PREC_F64;
     hipError_t oe;

@@ -33,6 +33,7 @@ namespace {
 constexpr int SG_NS = 64;                 // stages a workgroup can hold
 constexpr int SG_NT = 256, SG_NW = 4;     // one lane per leg-stage
 constexpr int SG_NQ = 6 * SG_NS;
+constexpr double SG_ALPHA_FLOOR = 2e-5;   // where this engine's continuation of an alpha = 0 request ends (mpcqp_kernels.hip)
 // Workspace of one resident workgroup, in doubles: the fp64 chains' factor matrices, per stage  Lrow (128) | Lcol (128)  (the fp32
 // chains keep theirs in LDS for the whole ADMM block).
 constexpr int SG_WS_STAGE = 128 + 128;
@@ -256,8 +257,13 @@ __device__ __forceinline__ void sg_build_E(SmemS& s, const LegSys<double>& L, co
 template <typename TM>
 __device__ __forceinline__ void sg_leg_solve(SmemS& s, const double* __restrict__ ws, const LegSys<double>& L, const double (&rhs)[3], double (&x)[3],
                                              const bool leg, const int N, const int tid) {
+  using T2 = std::conditional_t<sizeof(TM) == 4, float2, double2>;
   const double d = s.delta, th = s.theta, gp = th * d * d, gq = d;
   const int kq = min(tid, 4 * N - 1) >> 2, lq = tid & 3;
+  // The recursion's vectors in the chains' element type (fp32 chains: the first half of the same bytes)
+  TM* const s0 = reinterpret_cast<TM*>(s.s0);
+  TM* const pist = reinterpret_cast<TM*>(s.pist);
+  TM* const zst = reinterpret_cast<TM*>(s.zst);
   double a[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) a[c] = L.dinv[c] * rhs[c];
@@ -277,10 +283,10 @@ __device__ __forceinline__ void sg_leg_solve(SmemS& s, const double* __restrict_
         double v = pg[0] * b[0];
 #pragma unroll
         for (int q = 1; q < 6; ++q) v = fma(pg[q], b[q], v);
-        s.s0[12 * kq + 2 * c + h] = v;
+        s0[12 * kq + 2 * c + h] = (TM)v;
       }
     }
-    if (tid < 12) { s.pist[12 * N + tid] = 0.0; s.zst[tid] = 0.0; }
+    if (tid < 12) { pist[12 * N + tid] = (TM)0; zst[tid] = (TM)0; }
     if constexpr (sizeof(TM) == 8) {   // fp64 chains: Lrow of all stages -> LDS
       double* fb = reinterpret_cast<double*>(s.fbuf);
       for (int e = tid; e < 128 * N; e += SG_NT) fb[e] = ws[(size_t)(e >> 7) * SG_WS_STAGE + (e & 127)];
@@ -291,38 +297,43 @@ __device__ __forceinline__ void sg_leg_solve(SmemS& s, const double* __restrict_
   const TM* const fcol = reinterpret_cast<const TM*>(s.fbuf) + (sizeof(TM) == 4 ? SG_NS * 128 : 0);
   if (tid < 64) {   // backward chain: group 0 of wave 0 (the other groups of the wave run along on the same data)
     const int c = tid & 7;
-    const TM msk = c < 6 ? (TM)1 : (TM)0;
+    const bool on6 = c < 6;
+    const TM tgp = (TM)gp, tgq = (TM)gq, td = (TM)d;
     TM pp = 0, pq = 0;
-    TM Lr[16];
+    TM LA[16], LB[16];
     {
       const TM* f = frow + 128 * (N - 1) + 16 * c;
 #pragma unroll
-      for (int t = 0; t < 16; ++t) Lr[t] = f[t];
+      for (int t = 0; t < 16; ++t) LA[t] = f[t];
     }
-    double2 sn = *reinterpret_cast<const double2*>(s.s0 + 12 * (N - 1) + 2 * c);
-#pragma unroll 1
-    for (int k = N - 1; k >= 1; --k) {
-      TM Ln[16];
+    T2 sA = *reinterpret_cast<const T2*>(s0 + 12 * (N - 1) + 2 * c), sB;
+    // one step: stage k with (Lr, sn), while the rows and the pair of stage k - 1 are fetched into (Ln, sn2) -- two register sets
+    // that swap roles from step to step (no copies)
+    auto step = [&](const int k, const TM (&Lr)[16], const T2& sn, TM (&Ln)[16], T2& sn2) {
       {
         const TM* f = frow + 128 * (k - 1) + 16 * c;   // (stage 0's are loaded and not used)
 #pragma unroll
         for (int t = 0; t < 16; ++t) Ln[t] = f[t];
       }
-      const double2 sn2 = *reinterpret_cast<const double2*>(s.s0 + 12 * (k - 1) + 2 * c);
-      TM sp = fma(msk, (TM)sn.x, pp), sq = fma(msk, (TM)sn.y, pq);
-      const TM cc = (TM)gp * sp + (TM)gq * sq;
+      sn2 = *reinterpret_cast<const T2*>(s0 + 12 * (k - 1) + 2 * c);
+      // (lanes 6, 7 of the group hold no component: what they read past the stage's twelve entries is SELECTED away, never multiplied
+      //  by zero -- the bytes behind the last stage are whatever the previous kernel left in LDS, and 0 x NaN would reach lanes 0..5
+      //  through the butterfly: 8 of the 1000 logged ticks came back NaN from one launch before this was a select)
+      TM sp = (on6 ? sn.x : (TM)0) + pp, sq = (on6 ? sn.y : (TM)0) + pq;
+      const TM cc = tgp * sp + tgq * sq;
       TM g[8];
       xor_gather8(cc, g);
       TM a0 = 0, a1 = 0, b0 = 0, b1 = 0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) { a0 = fma(Lr[t], g[t], a0); a1 = fma(Lr[4 + t], g[4 + t], a1); b0 = fma(Lr[8 + t], g[t], b0); b1 = fma(Lr[12 + t], g[4 + t], b1); }
       sp -= a0 + a1; sq -= b0 + b1;
-      pp = sp; pq = fma((TM)d, sp, sq);
-      if (tid < 6) *reinterpret_cast<double2*>(s.pist + 12 * k + 2 * c) = make_double2((double)pp, (double)pq);
-#pragma unroll
-      for (int t = 0; t < 16; ++t) Lr[t] = Ln[t];
-      sn = sn2;
-    }
+      pp = sp; pq = fma(td, sp, sq);
+      if (tid < 6) { T2 w; w.x = pp; w.y = pq; *reinterpret_cast<T2*>(pist + 12 * k + 2 * c) = w; }
+    };
+    int k = N - 1;
+#pragma unroll 1
+    for (; k >= 2; k -= 2) { step(k, LA, sA, LB, sB); step(k - 1, LB, sB, LA, sA); }
+    if (k == 1) step(1, LA, sA, LB, sB);
   }
   __syncthreads();
   // d_k = b_k - E_k Gam' pi_{k+1} -> P slots of s0  (fp64 chains: Lcol of all stages -> LDS; the backward chain is done with Lrow)
@@ -333,35 +344,34 @@ __device__ __forceinline__ void sg_leg_solve(SmemS& s, const double* __restrict_
   for (int e = tid; e < 6 * N; e += SG_NT) {
     const int k = e / 6, c = e - 6 * k;
     const double* Ek = s.Es + 36 * k + 6 * c;
-    const double* pk = s.pist + 12 * (k + 1);
+    const TM* pk = pist + 12 * (k + 1);
     double acc = s.bq[e];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) acc -= Ek[q] * (gp * pk[2 * q] + gq * pk[2 * q + 1]);
-    s.s0[12 * k + 2 * c] = acc;
+    for (int q = 0; q < 6; ++q) acc -= Ek[q] * (gp * (double)pk[2 * q] + gq * (double)pk[2 * q + 1]);
+    s0[12 * k + 2 * c] = (TM)acc;
   }
   __syncthreads();
   if (tid < 64) {   // forward chain
     const int c = tid & 7;
-    const TM msk = c < 6 ? (TM)1 : (TM)0;
+    const bool on6 = c < 6;
+    const TM tgp = (TM)gp, tgq = (TM)gq, td = (TM)d;
     TM zp = 0, zq = 0;
-    TM Lc[16];
+    TM LA[16], LB[16];
     {
       const TM* f = fcol + 16 * c;
 #pragma unroll
-      for (int t = 0; t < 16; ++t) Lc[t] = f[t];
+      for (int t = 0; t < 16; ++t) LA[t] = f[t];
     }
-    double dn = s.s0[2 * c];
-#pragma unroll 1
-    for (int k = 0; k < N; ++k) {
-      TM Ln[16];
+    TM dA = s0[2 * c], dB;
+    auto step = [&](const int k, const TM (&Lc)[16], const TM dn, TM (&Ln)[16], TM& dn2) {
       {
         const TM* f = fcol + 128 * min(k + 1, N - 1) + 16 * c;
 #pragma unroll
         for (int t = 0; t < 16; ++t) Ln[t] = f[t];
       }
-      const double dn2 = s.s0[12 * min(k + 1, N - 1) + 2 * c];
-      const TM dk = msk * (TM)dn;
-      const TM tp = zp + (TM)d * zq + (TM)gp * dk, tq = zq + (TM)gq * dk;
+      dn2 = s0[12 * min(k + 1, N - 1) + 2 * c];
+      const TM dk = on6 ? dn : (TM)0;
+      const TM tp = zp + td * zq + tgp * dk, tq = zq + tgq * dk;
       TM g0[8], g1[8];
       xor_gather8(tp, g0);
       xor_gather8(tq, g1);
@@ -369,23 +379,24 @@ __device__ __forceinline__ void sg_leg_solve(SmemS& s, const double* __restrict_
 #pragma unroll
       for (int t = 0; t < 4; ++t) { a0 = fma(Lc[t], g0[t], a0); a1 = fma(Lc[4 + t], g0[4 + t], a1); b0 = fma(Lc[8 + t], g1[t], b0); b1 = fma(Lc[12 + t], g1[4 + t], b1); }
       const TM o = (a0 + a1) + (b0 + b1);
-      zp = tp - (TM)gp * o; zq = tq - (TM)gq * o;
-      if (tid < 6) *reinterpret_cast<double2*>(s.zst + 12 * (k + 1) + 2 * c) = make_double2((double)zp, (double)zq);
-#pragma unroll
-      for (int t = 0; t < 16; ++t) Lc[t] = Ln[t];
-      dn = dn2;
-    }
+      zp = tp - tgp * o; zq = tq - tgq * o;
+      if (tid < 6) { T2 w; w.x = zp; w.y = zq; *reinterpret_cast<T2*>(zst + 12 * (k + 1) + 2 * c) = w; }
+    };
+    int k = 0;
+#pragma unroll 1
+    for (; k + 1 < N; k += 2) { step(k, LA, dA, LB, dB); step(k + 1, LB, dB, LA, dA); }
+    if (k < N) step(k, LA, dA, LB, dB);
   }
   __syncthreads();
   {   // y_k = PG_k' z_{k+1} + Gam' pi_{k+1}: lanes 0..2 of the quad take two components each, DPP hands them round
-    const double* zk = s.zst + 12 * (kq + 1);
-    const double* pk = s.pist + 12 * (kq + 1);
+    const TM* zk = zst + 12 * (kq + 1);
+    const TM* pk = pist + 12 * (kq + 1);
     const int c0 = 2 * min(lq, 2);
-    double y0 = gp * pk[2 * c0] + gq * pk[2 * c0 + 1], y1 = gp * pk[2 * c0 + 2] + gq * pk[2 * c0 + 3];
+    double y0 = gp * (double)pk[2 * c0] + gq * (double)pk[2 * c0 + 1], y1 = gp * (double)pk[2 * c0 + 2] + gq * (double)pk[2 * c0 + 3];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {   // PG row i = 6 h + c multiplies z slot 2 c + h
       const int h = i >= 6 ? 1 : 0, c = i - 6 * h;
-      const double zv = zk[2 * c + h];
+      const double zv = (double)zk[2 * c + h];
       y0 = fma(s.PGs[72 * kq + 6 * i + c0], zv, y0);
       y1 = fma(s.PGs[72 * kq + 6 * i + c0 + 1], zv, y1);
     }
@@ -629,7 +640,7 @@ __device__ __forceinline__ int sg_polish_round(SmemS& s, const DevCfg& cfg, SLeg
       for (int k = 0; k < min(ps, 32); ++k) seen = seen || s.ahist[k] == h;
       __syncthreads();
       if (tid == 0 && ps < 32) s.ahist[ps] = h;
-      if (seen) break;   // uniform
+      if (seen && !last) break;   // uniform (a round that nothing follows goes on: mpcqp_wrench.h)
     }
     const ActSet as(code, Lg.stance);
     LegSys<double> Ls;
@@ -659,7 +670,10 @@ __device__ __forceinline__ int sg_polish_round(SmemS& s, const DevCfg& cfg, SLeg
       const float gmaxl = s.gmax;
       const float tol_stat = 1e-6f + 1e-9f * gmaxl;
       const float tol = fminf(tol_stat, 0.25f * 2.f * (float)s.alpha * 2e-5f * fmaxf(1.f, q[1]));
-      if (stat <= tol || rf >= 4 || (rf > 0 && !(stat < 0.5f * prev))) break;   // uniform
+      // (the recursion's solve is as exact as cond(S) eps -- 1e-13 at alpha = 1e-2, 1e-6 at 3e-6, tools/stage_proto.py -- and the Woodbury
+      //  form amplifies that by the cancellation in dinv (rhs - A'y): small regularisers get more refinement steps)
+      const int rf_max = s.alpha < 1e-3 ? 12 : 4;
+      if (stat <= tol || rf >= rf_max || (rf > 0 && !(stat < 0.5f * prev))) break;   // uniform
       const double rhs[3] = {-rg[0], -rg[1], -rg[2]};
       double dx[3];
       sg_leg_solve<double>(s, ws, Ls, rhs, dx, Lg.leg, N, tid);

@@ -759,6 +759,7 @@ constexpr double ALPHA_FLOOR = 3e-6;    // where a request for alpha = 0 ends (t
 #ifndef MPCQP_W_POLISH_PATIENCE
 #define MPCQP_W_POLISH_PATIENCE 1
 #endif
+constexpr int POLISH_CHEAP_LEGS = 3;    // ... on at most this many changed leg-stages (a changed leg-stage costs up to six rank-one updates, ~3.7 us)
 constexpr int POLISH_CHEAP_STEPS = 0;   // further steps of a round beyond the patience rule while they only update the inverse
 constexpr int POLISH_PATIENCE = MPCQP_W_POLISH_PATIENCE;   // polish steps that may fail to halve the KKT violation before the round gives up
 #ifndef MPCQP_W_ADAPT_AT
@@ -1004,7 +1005,7 @@ __device__ __forceinline__ unsigned w_aset_hash(SmemW<TV, N>& s, const int tid) 
 template <typename TV, typename TP, int N>
 __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tabs, const TP* __restrict__ kinvT, const int tid0,
                                               const int budget, const bool last, const int trace_tag, const int incr_legs,
-                                              const int patience, const int cheap_steps) {
+                                              const int patience, const int cheap_steps, const int cheap_legs) {
   constexpr int NL = WG<N>::NL, NW = WG<N>::NW, G = WG<N>::G;
   constexpr int STG = 2 * 21 + 1;   // staging record of a changed leg-stage in s.E: removed | added {A[3][6], weight[3]}, stage index
   static_assert(STG * MPCQP_W_INCR_LEGS <= N * 36, "the staging records share the bytes of E");
@@ -1223,14 +1224,16 @@ __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tab
           for (int k = 0; k < min(ps, 32); ++k) seen = seen || s.ahist[k] == h;
           if (tid == 0 && ps < 32) s.ahist[ps] = h;
           wsync<NW>();
-          if (seen) { done = true; break; }   // uniform
+          // (not in a round that nothing follows: at small regularisers the solve is only as exact as its refinement, and a second
+          //  visit of an active set starts that refinement from a better point -- the alpha = 0 continuation lost 1 % of its QPs to this test)
+          if (seen && !last) { done = true; break; }   // uniform
         }
         // ... and a round whose steps have stopped making progress ends -- unless the next step is a cheap one (its active set
         // differs on few leg-stages, so -S^-1 is updated, not rebuilt: ~4 us against the ~85 us of another ADMM round; the hardest
         // QP of the bench batch repeated the same two candidates in three rounds, one step short of its optimum each time,
         // tools/hardest.py), for up to `cheap_steps` such steps per round.
         if (nstall >= patience && !last) {
-          if (incr && cheap_used < cheap_steps) ++cheap_used;
+          if (incr && nupd <= cheap_legs && cheap_used < cheap_steps) ++cheap_used;
           else { done = true; break; }   // uniform
         }
       }
@@ -1440,7 +1443,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
 #else
       const int trace_tag = -1;
 #endif
-      if (budget > 0) ok = __builtin_amdgcn_readfirstlane(w_polish_round<TV, TP, N>(s, tabs, kinvP, tid0, budget, last, trace_tag, cfg.incr_legs, cfg.patience, cfg.cheap_steps));
+      if (budget > 0) ok = __builtin_amdgcn_readfirstlane(w_polish_round<TV, TP, N>(s, tabs, kinvP, tid0, budget, last, trace_tag, cfg.incr_legs, cfg.patience, cfg.cheap_steps, cfg.cheap_legs));
       if (ok == 1 && s.alpha > s.alpha_target) {   // next continuation level, from this optimum and its multipliers
         const int tid = fresh_tid<NW>(tid0);
         for (int i = tid; i < n; i += NT) s.ua[i] = s.uv[i];            // the last accepted answer and its multipliers (the ADMM
