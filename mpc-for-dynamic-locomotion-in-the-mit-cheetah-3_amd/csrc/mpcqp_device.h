@@ -49,6 +49,7 @@ struct DevCfg {
   int patience;         // wrench engine: polish steps of a round that may fail to halve the KKT violation before the round gives up
   int cheap_steps;      // wrench engine: ... and the steps a round may go on beyond that while they only update the inverse
   int cheap_legs;       // wrench engine: ... on at most this many changed leg-stages
+  int refine_admm;      // all-fp64 ADMM without polish at tolerances below 1e-6: one refinement step per linear solve
 };
 
 // Problem constants staged in LDS in the vector precision (keeps ~100 scalar registers free).

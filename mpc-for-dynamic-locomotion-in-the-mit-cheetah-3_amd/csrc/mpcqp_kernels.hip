@@ -277,6 +277,9 @@ hipError_t launch_wrench(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void
   if (e->cfg.precision == MPCQP_PREC_MIXED)
     hipLaunchKernelGGL((mpcqp_wrench_solve<double, float, double, TIO, N>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
                        (TIO*)X, st, it, res, ob, (int)B);
+  else if (e->dev.refine_admm)   // tight-tolerance ADMM-only runs: the instantiation with a refinement step per linear solve
+    hipLaunchKernelGGL((mpcqp_wrench_solve<double, double, double, TIO, N, true>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
+                       (TIO*)X, st, it, res, ob, (int)B);
   else
     hipLaunchKernelGGL((mpcqp_wrench_solve<double, double, double, TIO, N>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
                        (TIO*)X, st, it, res, ob, (int)B);
@@ -542,6 +545,7 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   d.patience = cfg->polish_patience > 0 ? cfg->polish_patience : POLISH_PATIENCE;
   d.cheap_steps = cfg->polish_cheap_steps > 0 ? cfg->polish_cheap_steps : (cfg->polish_cheap_steps < 0 ? 0 : POLISH_CHEAP_STEPS);
   d.cheap_legs = cfg->polish_cheap_legs > 0 ? cfg->polish_cheap_legs : POLISH_CHEAP_LEGS;
+  d.refine_admm = (!(cfg->flags & MPCQP_FLAG_POLISH) && cfg->precision == MPCQP_PREC_F64 && cfg->eps_abs < 1e-6) ? 1 : 0;
 
   // coefficient tables: c0[j][j'] = delta^2 (N - max(j,j')),
   // c1[j][j'] = delta^4 sum_{k > max(j,j')}^{N} (k-1-j+theta)(k-1-j'+theta)

@@ -583,6 +583,18 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
         const double rhs[3] = {fma(r, w0, fma(sigma, u[0], -Lg.g[0])), fma(r, w1, fma(sigma, u[1], -Lg.g[1])), fma(r, w2, fma(sigma, u[2], -Lg.g[2]))};
         double ut[3];
         sg_leg_solve<TM>(s, ws, Ls, rhs, ut, Lg.leg, N, tid);
+        if constexpr (sizeof(TM) == 8) {
+          if (cfg.refine_admm) {   // tight-tolerance ADMM-only runs: one refinement step on M u~ = rhs (mpcqp_wrench.h)
+            double hv[3], rr[3], du[3];
+            sg_grad(s, Lg, ut, hv, N, tid);   // H u~ + g
+            const double dg[3] = {2.0, 2.0, 1.0 + 4.0 * mu * mu};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) rr[a] = rhs[a] - ((hv[a] - Lg.g[a]) + (sigma + r * dg[a]) * ut[a]);
+            sg_leg_solve<TM>(s, ws, Ls, rr, du, Lg.leg, N, tid);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ut[a] += du[a];
+          }
+        }
         const double mz = mu * ut[2];
         const double gt[5] = {ut[2], ut[0] - mz, ut[0] + mz, ut[1] - mz, ut[1] + mz};
 #pragma unroll

@@ -760,7 +760,11 @@ constexpr double ALPHA_FLOOR = 3e-6;    // where a request for alpha = 0 ends (t
 #define MPCQP_W_POLISH_PATIENCE 1
 #endif
 constexpr int POLISH_CHEAP_LEGS = 3;    // ... on at most this many changed leg-stages (a changed leg-stage costs up to six rank-one updates, ~3.7 us)
-constexpr int POLISH_CHEAP_STEPS = 0;   // further steps of a round beyond the patience rule while they only update the inverse
+constexpr int POLISH_CHEAP_STEPS = 3;   // further steps of a round beyond the patience rule while they only update the inverse on few leg-stages
+                                        // (seven batches of other seeds than the bench's, tools/patience_sweep.py, profiles/r03_cheap_sweep.txt:
+                                        //  3 steps on <= 3 leg-stages: +7.9 % on their mean at B = 4096; <= 5 leg-stages: -3 %; without the
+                                        //  leg limit -- any step that updates, up to 8 leg-stages -- no gain: a changed leg-stage costs up to six
+                                        //  rank-one updates, and a futile step on five of them costs as much as the rebuild it avoids)
 constexpr int POLISH_PATIENCE = MPCQP_W_POLISH_PATIENCE;   // polish steps that may fail to halve the KKT violation before the round gives up
 #ifndef MPCQP_W_ADAPT_AT
 #define MPCQP_W_ADAPT_AT 25
@@ -788,7 +792,7 @@ __device__ __forceinline__ void w_admm_sys(const SmemW<TV, N>& s, const DevCfg& 
 // only); a QP that triggers it gets rho <- rho * ratio, a rebuilt matrix and a longer block.  Updates s.rho / s.iters /
 // s.hard / s.ratio and leaves the new iterate in s.ua/za/ya and s.pu/py.
 // Register phases that share nothing but LDS (see w_polish): E | tile + sweep | iterations.
-template <typename TV, typename TM, int N>
+template <typename TV, typename TM, int N, bool REFINE = false>
 __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const WrTabs& tabs, const TM* __restrict__ kinvT, const int adapt,
                                        const int kfirst, const int tid0) {
   constexpr int NL = WG<N>::NL, NW = WG<N>::NW, G = WG<N>::G;
@@ -863,6 +867,28 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
                              fma(r, w2, fma(sigma, A.u[2], -A.g[2]))};
           TM ut[3];
           w_solve<TM, N>(tile, Ls, rhs, ut, bv, cv, tid, gr, gc);
+          if constexpr (REFINE) {
+            // (own instantiation of the kernel, REFINE = true: the extra live values cost the all-fp64 kernel 85 more spilled registers)
+            // ADMM that has to converge by itself to tight tolerances (polish off, eps below ~1e-6): one step of iterative refinement
+            // on  M u~ = rhs,  M = (2 alpha + sigma) I + rho G'G + T'KT,  with the structured product -- the explicit swept inverse is
+            // exact to ~1e-10, which left the dual residual of one QP in 32 stalled a decade above eps = 1e-9 (round-2 advisor)
+            {
+              if (leg) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) s.uv[3 * L + a] = (TV)ut[a];
+              }
+              wsync<NW>();
+              TV hv[3];
+              w_grad<TV, N>(s, tabs.K, tid, hv);   // H u~ + g
+              const TM dg[3] = {(TM)2, (TM)2, (TM)1 + (TM)4 * A.mu * A.mu};
+              TM rr[3], du[3];
+#pragma unroll
+              for (int a = 0; a < 3; ++a) rr[a] = rhs[a] - (((TM)hv[a] - A.g[a]) + (sigma + r * dg[a]) * ut[a]);
+              w_solve<TM, N>(tile, Ls, rr, du, bv, cv, tid, gr, gc);
+#pragma unroll
+              for (int a = 0; a < 3; ++a) ut[a] += du[a];
+            }
+          }
           const TM mz = A.mu * ut[2];
           const TM gt[5] = {ut[2], ut[0] - mz, ut[0] + mz, ut[1] - mz, ut[1] + mz};
 #pragma unroll
@@ -1336,7 +1362,7 @@ __device__ __forceinline__ void w_output(SmemW<TV, N>& s, const WrTabs& tabs, TI
 // of the dearest-expected-first order that the pre-pass of mpcqp_fast.h files; the hardware's dispatcher places the workgroups.
 // Queued form (ob.head != null): only as many workgroups as the device holds, each pulling QPs from the head of that order until
 // it is empty (no workgroup turnover: the form for batches many times the device).
-template <typename TV, typename TM, typename TP, typename TIO, int N>
+template <typename TV, typename TM, typename TP, typename TIO, int N, bool REFINE = false>
 __global__ void __launch_bounds__(WG<N>::NT, 2)
 mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const FastIn<TIO> in, TIO* ug, TIO* __restrict__ Xg,
                    int* __restrict__ statusg, int* __restrict__ itersg, float* __restrict__ resg, const OrderBuf ob, const int Btot) {
@@ -1431,7 +1457,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       int budget = kind == R_WARM ? min(warm_tries, polish_max) : 2 * polish_max;
       const bool admm_only = !(cfg.flags & MPCQP_FLAG_POLISH);
       if (kind == R_ADMM) {
-        w_admm<TV, TM, N>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, round == 0 ? (warm >= 2 ? (cfg.first_block > 0 ? min(WARM_K, (6 * cfg.first_block) / 10) : WARM_K) : cfg.first_block) : 0, tid0);
+        w_admm<TV, TM, N, REFINE>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, round == 0 ? (warm >= 2 ? (cfg.first_block > 0 ? min(WARM_K, (6 * cfg.first_block) / 10) : WARM_K) : cfg.first_block) : 0, tid0);
         budget = admm_only ? 0 : (__builtin_amdgcn_readfirstlane(s.hard) ? HARD_POLISH_FACTOR : 1) * polish_max;
       }
       // Active-set steps while they make progress: a step that does not at least halve the KKT violation of the previous one

@@ -81,6 +81,38 @@ def test_single_robot_receding_horizon_surface(oracle_solve):
     assert rel_err(out["u"].cpu().numpy(), ref["u"]).max() <= 1e-4
 
 
+def test_reference_parameters_closed_loop():
+    """The reference's own `params` (src/main.py:31-46: N = 60, world_time_step = 0.01, ss / ds = 10 / 5 ticks, first_swing
+    [0, 0, 1, 1], v_com_ref 0.18) through MPC.solve(t, logger) on the device -- the stage-wise engine -- for 120 ticks of the kinematic
+    stand-in: same surface, logger hooks at t = 0 and 80 with the reference's 12 x 61 / 4 x 60 shapes, tracking on every tick."""
+    params = {"g": -9.81, "h": 0.285, "step_height": 0.08, "ss_duration": 10, "ds_duration": 5, "world_time_step": 0.01,
+              "total_steps": 20, "first_swing": np.array([0, 0, 1, 1]), "µ": 1, "N": 60, "dof": 18,
+              "v_com_ref": np.array([0.18, 0.0, 0.0]), "theta_dot": 0.0, "log_samples": 1000}
+    feet = mpcqp.synth.NOMINAL_FEET + np.array([0.0, 0.0, 0.285])
+    initial = {l: feet[k].copy() for k, l in enumerate(LEGS)}
+    initial.update(roll=0.0, pitch=0.0, yaw=0.0, com_position=np.array([0.0, 0.0, 0.285]))
+    planner = FootstepPlanner(initial, params, show=False)
+    robot = KinematicLite3(planner, np.array([0, 0, 0, 0, 0, 0.285, 0, 0, 0, 0, 0, 0], float))
+    mpc = MPC(lite3=robot, initial=initial, footstep_planner=planner, params=params)
+    logger = Logger({"params": params, "total_sim_steps": 120})
+    xs = []
+    for t in range(120):
+        robot.t = t
+        forces = mpc.solve(t, logger)
+        assert mpc.status == 1 and mpc.x_log.shape == (12, 61) and mpc.u_plot.shape == (12, 60)
+        phase = planner.get_phase_at_time(t)
+        for k, l in enumerate(LEGS):                              # swing legs carry no force, stance legs at least f_min
+            assert (forces[l][2] >= 3.0 - 1e-6) if phase[k] else np.all(forces[l] == 0.0)
+        robot.x = mpc.x_log[:, 1].copy()
+        xs.append(robot.x.copy())
+    xs = np.array(xs)
+    assert [p["time step"] for p in logger.log["MPC PREDICTIONS"]] == [0, 80]
+    assert logger.log["MPC PREDICTIONS"][1]["predicted_state"].shape == (12, 61)
+    assert logger.log["MPC PREDICTIONS"][1]["predicted forces"].shape == (4, 60)
+    assert np.abs(xs[:, 5] - 0.285).max() < 0.02 and abs(xs[40:, 9].mean() - 0.18) < 0.05
+    assert np.abs(xs[:, 1]).max() < 0.1 and np.abs(xs[:, 0]).max() < 0.1
+
+
 def test_warm_started_controller_matches_cold_one():
     """MPC(..., warm_start=True) -- the reference's `opt.set_initial(U, sol.value(U))` (src/mpc.py:270-271), with the engine
     carrying the solution and its multipliers from tick to tick -- must command the same forces as the cold controller on

@@ -140,15 +140,18 @@ def test_alpha0_continuation_on_config3(oracle_solve):
         assert abs(J - Jr) <= 1e-6 * max(1.0, abs(Jr))
 
 
-def test_admm_only_converges_to_oracle(oracle_solve):
-    """No polish: plain ADMM in f64 run long enough reaches the oracle (the polish is an accelerator, not a crutch)."""
+@pytest.mark.parametrize("engine", ["wrench", "stage"])
+def test_admm_only_converges_to_oracle(oracle_solve, engine):
+    """No polish -- the mode the reference runs (OSQP, src/mpc.py:51-55): plain ADMM in f64 run long enough reaches the oracle on
+    EVERY QP (the polish is an accelerator, not a crutch).  Tolerances below 1e-6 switch on one refinement step per linear solve
+    (round-2 advisor: without it the explicit inverse left one dual residual in 32 stalled a decade above eps = 1e-9)."""
     b = mpcqp.synth.config2(32)
     ref = oracle_solve(b)
-    out = gpu_solve(b, precision="f64", flags=0, max_iter=20000, check_every=100, eps_abs=1e-9, eps_rel=1e-9)
-    conv = out["status"] == 2
-    assert conv.mean() >= 0.95                                   # (an occasional QP needs more than 20 000 iterations for 1e-9)
-    assert rel_err(out["u"], ref["u"])[conv].max() <= 1e-4
-    assert rel_err(out["u"], ref["u"]).max() <= 1e-2             # ... and is close all the same
+    flags = mpcqp.FLAG_STAGE_KERNEL if engine == "stage" else 0
+    out = gpu_solve(b, precision="f64", flags=flags, max_iter=20000, check_every=100, eps_abs=1e-9, eps_rel=1e-9)
+    assert np.all(out["status"] == 2), (out["status"].tolist(), out["iters"].tolist())
+    assert rel_err(out["u"], ref["u"]).max() <= 1e-4
+    assert out["iters"].max() <= 10000                            # (the emulation in exact arithmetic needs at most 1100)
 
 
 def test_full_size_properties():

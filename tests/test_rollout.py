@@ -72,6 +72,43 @@ def test_oracle_rollout_tracks_the_reference(oracle_lib):
     assert np.abs(a[:, :, 3] - dsr[:, :, 3]).max() < 0.05                            # com x follows the rolled-forward reference
 
 
+def _malformed(rb):
+    """Plan rows no planner would write: zero steps, zero-length steps, a step count beyond the table, negative durations and ticks."""
+    meta, tick = rb["plan_meta"].copy(), rb["tick"].copy()
+    meta[0] = (0, 4, 2, 0); meta[1] = (5, 0, 0, 0); meta[2] = (99, 4, 2, 0); meta[3] = (5, -3, -1, 0)
+    tick[4] = -7
+    return meta, tick
+
+
+def test_oracle_rollout_clamps_malformed_plan_rows(oracle_lib):
+    """include/mpcqp.h: the plan table is clamped (1 <= S_b <= S, ss >= 0, ss + ds >= 1, tick >= 0), never indexed with or divided by as
+    it stands -- a malformed row gives a finite, bounded roll-out, not a fault (round-2 advisor)."""
+    rb = mpcqp.synth.make_rollout_batch(6, total_steps=5, seed=3)
+    meta, tick = _malformed(rb)
+    out = _oracle_engine().rollout_host(rb["x"], rb["ref"], rb["plan_pos"], rb["plan_feet_id"], meta, tick, rb["mu"], 8)
+    assert np.all(np.isfinite(out["forces"])) and np.all(np.isfinite(out["x"])) and np.all(out["tick"] == tick + 8)
+    assert np.all(out["solved"] == 8)
+    # S_b = 0 is served as S_b = 1 (the first step, reference velocities gated off), S_b = 99 as the table's 5 steps
+    good = _oracle_engine().rollout_host(rb["x"], rb["ref"], rb["plan_pos"], rb["plan_feet_id"], rb["plan_meta"], rb["tick"], rb["mu"], 8)
+    assert np.array_equal(out["forces"][2], good["forces"][2]) and np.array_equal(out["forces"][5], good["forces"][5])
+
+
+@pytest.mark.gpu
+def test_device_rollout_clamps_malformed_plan_rows():
+    import torch
+    rb = mpcqp.synth.make_rollout_batch(6, total_steps=5, seed=3)
+    meta, tick = _malformed(rb)
+    ref = _oracle_engine().rollout_host(rb["x"], rb["ref"], rb["plan_pos"], rb["plan_feet_id"], meta, tick, rb["mu"], 8)
+    sol = mpcqp.MPCBatch(N=10, delta=0.03, io_dtype="f64", precision="mixed")
+    f = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda").contiguous()
+    x, rf, tk = f(rb["x"]), f(rb["ref"]), f(tick, torch.int32)
+    out = sol.rollout(x, rf, f(rb["plan_pos"]), f(rb["plan_feet_id"], torch.uint8), f(meta, torch.int32), tk, f(rb["mu"]), 8)
+    torch.cuda.synchronize()
+    assert np.array_equal(tk.cpu().numpy(), tick + 8) and np.all(out["solved"].cpu().numpy() == 8)
+    F = out["forces"].cpu().numpy()
+    assert np.all(np.isfinite(F)) and np.abs(F - ref["forces"]).max() <= 1e-4 * np.abs(ref["forces"]).max()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("warm", [False, True])
 def test_device_rollout_matches_oracle(warm):
