@@ -31,8 +31,9 @@ import mpcqp  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0        # HBM3E spec (6290 measured float4 copy)
-TRAFFIC_FILE = "r02_g_hbm_traffic.json"   # PMC passes of the current kernel (profiles/)
-SQ_FILE = "r02_g_pmc.txt"                   # SQ counter passes of the same kernel and workload (tools/pmc_run.sh)
+TRAFFIC_FILE = "r03_hbm_traffic.json"     # PMC passes of the current kernel (profiles/), FETCH_SIZE corrected by the round-3 calibration
+SQ_FILE = "r03_pmc.txt"                     # SQ counter passes of the same kernel and workload (tools/pmc_run.sh)
+FLOPS_FILE = "r03_flops.json"               # floating-point instruction mix of the same kernel and workload (tools/pmc_flops.sh)
 PEAK_VALU_ISSUE = 1024 * 2.4e9 / 4          # wave-instructions/s: 1024 SIMDs, one wave64 vector instruction per 4 cycles (an fp64 FMA: 8)
 
 
@@ -110,7 +111,9 @@ def gait_breakdown(solver, N, delta, B, steps=5, precision="mixed"):
     # the workload of `value` drawn with other seeds: a launch of 4096 is as long as its few longest QPs, so the rate moves with
     # the draw (the solver's thresholds were chosen on such batches, not on the one `value` is quoted on)
     cases += [(f"mixed_seed_{sd}", allg, None, sd) for sd in (1, 2, 3, 4)]
+    note = lambda m: print(f"[bench breakdown] {m}", file=sys.stderr, flush=True)   # (progress on stderr: a fault names its piece)
     for name, gaits, force_contact, seed in cases:
+        note(name)
         b = mpcqp.synth.make_batch(B, N, delta, seed, gaits, (0.3, 0.5, 0.7, 1.0))
         if force_contact is not None:
             b["contact"][:] = 1
@@ -129,6 +132,7 @@ def gait_breakdown(solver, N, delta, B, steps=5, precision="mixed"):
     # the same engine on a batch that fills the device many times over (BASELINE config 4's 65 536 QPs on ONE GPU): the rate when
     # the launch is not as long as its longest QPs
     big = 65536
+    note("mixed_batch_65536")
     b = mpcqp.synth.make_batch(big, N, delta, 20250810, ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0))
     dev = solver.upload(b)
     for _ in range(2):
@@ -143,6 +147,7 @@ def gait_breakdown(solver, N, delta, B, steps=5, precision="mixed"):
     st = o["status"].cpu().numpy()
     out["mixed_batch_65536"] = {"qp_per_s": big * 3 / (e0.elapsed_time(e1) * 1e-3), "solved_fraction": float(((st == 1) | (st == 2)).mean())}
     # the reference's arithmetic is all-fp64: the same workload with every tile, vector and residual in fp64
+    note("f64_b4096")
     try:
         s64 = mpcqp.MPCBatch(N=N, delta=delta, device=solver.device.index, io_dtype="f32", precision="f64", flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)
         b = mpcqp.synth.make_batch(B, N, delta, 20250809, allg, (0.3, 0.5, 0.7, 1.0))
@@ -164,6 +169,7 @@ def gait_breakdown(solver, N, delta, B, steps=5, precision="mixed"):
         out["f64_b4096"] = {"error": repr(e)}
     # the reference's OWN configuration (N = 60, delta = 0.01, src/main.py:37,41) on the stage-wise engine: secondary, a different
     # horizon than the metric's -- the reference's figure for this setting is 61 solves/s on its CPU
+    note("reference_horizon_n60_b1024")
     try:
         Bn = 1024
         s60 = mpcqp.MPCBatch(N=60, delta=0.01, device=solver.device.index, io_dtype="f32", precision=precision, flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)
@@ -186,6 +192,7 @@ def gait_breakdown(solver, N, delta, B, steps=5, precision="mixed"):
     # two independent batches of B in flight: two handles on two HIP streams (a handle serves one stream at a time,
     # include/mpcqp.h).  The tail of one launch is filled by the head of the other -- what a caller with more than one fleet gets per
     # batch of B.  NOT `value`: that is one batch per step on one stream.
+    note("two_batches_two_streams")
     try:
         sols = [solver, mpcqp.MPCBatch(N=N, delta=delta, device=solver.device.index, io_dtype="f32", precision=precision,
                                        flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)]
@@ -225,6 +232,7 @@ def main():
     ap.add_argument("--distinct-shards", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--same-shards", action="store_true", help="N > 1, weak mode: every rank solves the configured batch (seed 20250809) instead of its own draw")
     ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: this many QPs in total (config-4 distribution), sharded contiguously over the ranks")
+    ap.add_argument("--first-block", type=int, default=0, help="MpcQpConfig.first_block (0: the engine's default; tools/first_block_sweep.sh)")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the secondary per-gait / all-stance figures")
@@ -274,7 +282,7 @@ def main():
     # (MPCQP_FLAG_NO_TIMING: the engine's own per-call event pair is a diagnostic; the timed region below is bracketed by this
     #  script's events on the same stream)
     solver = mpcqp.MPCBatch(N=N, delta=delta, device=device_index, io_dtype="f32", precision=args.precision,
-                            flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)
+                            flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING, first_block=args.first_block)
     dev = solver.upload(batch)
     gathered = None
     if args.allgather and dist is not None:   # RCCL: device buffers over xGMI; gloo (1-GPU rehearsals): through host memory
@@ -358,6 +366,20 @@ def main():
                         break
         except (OSError, ValueError, IndexError):
             pass
+        # executed work next to the algorithmic count (round-2 review): the wrench-space form executes fewer flops than the condensed
+        # formulation SURVEY 8(d) prices, so `frac` above is notional; the instruction mix comes from committed counter passes
+        executed = None
+        try:
+            if B == 4096 and args.precision == "mixed":
+                fj = json.load(open(os.path.join(REPO, "profiles", FLOPS_FILE)))
+                ex_min, ex_max = fj["executed_flops_per_qp_min"], fj["executed_flops_per_qp_max"]
+                executed = {"executed_flops_per_qp": {"min": ex_min, "max": ex_max},
+                            "executed_over_algorithmic": {"min": ex_min / flops, "max": ex_max / flops},
+                            "executed_tflops": {"min": ex_min * B / (kernel_ms * 1e-3) / 1e12, "max": ex_max * B / (kernel_ms * 1e-3) / 1e12},
+                            "fp_share_of_valu_issue": fj["fp_share_of_valu_issue"], "fma_share_of_valu_issue": fj["fma_share_of_valu_issue"],
+                            "source": "profiles/" + FLOPS_FILE, "note": fj["note"]}
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "QP solves/sec (horizon=10, 4-contact Lite3) at batch=4096", "value": value, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -381,6 +403,8 @@ def main():
                          else "mpcqp_fast_solve<float,float>" if args.precision == "f32" else "mpcqp_wrench_solve<double,double,double>",
                          "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_qp": flops,
+                         "achieved_is": "notional: ALGORITHMIC flops of the condensed formulation (SURVEY 8d) over the measured duration; the engine executes fewer (see `executed`)",
+                         "executed": executed,
                          "hbm": {"achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS,
                                  "algorithmic_bytes_per_qp": algorithmic_bytes(N), "note": "non-binding roof (SURVEY 8d)"},
                          "valu_issue": issue},

@@ -18,8 +18,8 @@ if N == 10: cases.append(("64k", mpcqp.synth.config4(65536)))
 for name, batch in cases:
     B = len(batch["x0"])
     for thr in thrs:
-        os.environ["MPCQP_ADAPT_THR"] = str(thr)
         kw = {"polish_max": int(os.environ["SW_PM"])} if os.environ.get("SW_PM") else {}
+        kw["adapt_thr"] = float(thr)
         if os.environ.get("SW_CE"): kw.update(check_every=int(os.environ["SW_CE"]), max_iter=int(os.environ.get("SW_MI", "400")))
         sol = mpcqp.MPCBatch(N=N, delta=0.03, precision=prec, **kw)
         dev = sol.upload(batch)

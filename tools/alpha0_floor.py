@@ -15,8 +15,7 @@ r0 = o0.solve_batch_host(batch["x0"], batch["r"], batch["contact"], batch["xdes"
 cfg0 = S.QPConfig(N=10, delta=0.03, alpha=0.0)
 W0 = np.array([S.net_wrench(r0["u"][i], batch["r"][i], batch["contact"][i], cfg0) for i in range(B)])
 for floor in ("1e-5", "3e-6", "1e-6"):
-    os.environ["MPCQP_ALPHA_FLOOR"] = floor
-    sol = mpcqp.MPCBatch(N=10, delta=float(q["delta"]), precision="mixed", io_dtype="f64", alpha=0.0, max_iter=800)
+    sol = mpcqp.MPCBatch(N=10, delta=float(q["delta"]), precision="mixed", io_dtype="f64", alpha=0.0, max_iter=800, alpha_floor=float(floor))
     d = sol.upload(bg); o = sol.solve_batch(d["x0"], d["r"], d["contact"], d["xdes"], d["mu"], want_X=True); torch.cuda.synchronize()
     st = o["status"].cpu().numpy(); u = o["u"].cpu().numpy(); X = o["X"].cpu().numpy()
     dJ = [abs(S.objective(X[i], u[i], bg["xdes"][i], cfgg) - opt["N10_a0_J"][i]) / max(1, abs(opt["N10_a0_J"][i])) for i in range(10)]
