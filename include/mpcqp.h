@@ -128,6 +128,10 @@ typedef struct MpcQpConfig {
   int32_t polish_cheap_steps; /* ... and the further steps a round may take beyond that as long as each only UPDATES S^-1 on at most
                                  polish_cheap_legs changed leg-stages; 0: default, -1: none */
   int32_t polish_cheap_legs;  /* 0: default */
+  int32_t hard_block_x10;     /* a QP that the early rho check flags gets a first block this many TENTHS of first_block long; 0: default */
+  int32_t polish_last_patience; /* the polish patience of a round that nothing follows (iteration cap reached); 0: default (unlimited: the
+                                   round uses its whole budget at N = 20, 4 at N = 10), n > 0: gives up after n steps that fail to halve the KKT violation,
+                                   -1: unlimited */
   int32_t reserved0;
 } MpcQpConfig;
 

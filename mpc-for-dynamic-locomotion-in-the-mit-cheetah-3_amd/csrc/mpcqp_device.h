@@ -49,6 +49,8 @@ struct DevCfg {
   int patience;         // wrench engine: polish steps of a round that may fail to halve the KKT violation before the round gives up
   int cheap_steps;      // wrench engine: ... and the steps a round may go on beyond that while they only update the inverse
   int cheap_legs;       // wrench engine: ... on at most this many changed leg-stages
+  int hard_x10;         // wrench engine: first-block length of a QP the early rho check flags, in tenths of the normal first block
+  int last_patience;    // wrench engine: patience of a round that nothing follows (0: unlimited)
   int refine_admm;      // all-fp64 ADMM without polish at tolerances below 1e-6: one refinement step per linear solve
 };
 

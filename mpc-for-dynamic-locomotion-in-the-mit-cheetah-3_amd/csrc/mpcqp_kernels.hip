@@ -548,6 +548,14 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   // (horizon 10 only by default: at N = 20 an update of the 120 x 120 inverse costs four times as much, and config 5 lost 7 % with the rule on)
   d.cheap_steps = cfg->polish_cheap_steps > 0 ? cfg->polish_cheap_steps : (cfg->polish_cheap_steps < 0 || N > 10 ? 0 : POLISH_CHEAP_STEPS);
   d.cheap_legs = cfg->polish_cheap_legs > 0 ? cfg->polish_cheap_legs : POLISH_CHEAP_LEGS;
+  // A QP that the early rho check flags gets a first block three times the normal one at horizon 10 (seven batches of other seeds than
+  // the bench's, tools/patience_sweep.py, profiles/r03_hard_block_sweep.txt: x2 / x2.5 / x3 / x3.5 -> 8.62 / 8.63 / 9.15 / 9.13 M QP/s on
+  // their mean at B = 4096: fewer of them need a third round, and the launch is as long as its longest QP; B = 65 536 pays 3 % for the
+  // extra iterations).  Horizon 20 keeps x2 (not re-swept).
+  d.hard_x10 = cfg->hard_block_x10 > 0 ? cfg->hard_block_x10 : (N > 10 ? 10 * HARD_ITER_FACTOR : 30);
+  // The round that nothing follows (iteration cap reached) used to run its whole polish budget; it now gives up after four steps that
+  // fail to halve the KKT violation (horizon 10: 9.04 -> 9.35 M on the held-out mean, the same QPs solved, profiles/r03_last_patience_sweep.txt)
+  d.last_patience = cfg->polish_last_patience > 0 ? cfg->polish_last_patience : (cfg->polish_last_patience < 0 || N > 10 ? 0 : 4);
   d.refine_admm = (!(cfg->flags & MPCQP_FLAG_POLISH) && cfg->precision == MPCQP_PREC_F64 && cfg->eps_abs < 1e-6) ? 1 : 0;
 
   // coefficient tables: c0[j][j'] = delta^2 (N - max(j,j')),

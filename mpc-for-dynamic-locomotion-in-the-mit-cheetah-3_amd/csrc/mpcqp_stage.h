@@ -625,7 +625,7 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
     if (!rebuild) break;
     rho = fminf(rho * ratio, ADAPT_RHO_MAX);
     hard = 1;
-    K = max(K, min(HARD_ITER_FACTOR * K, cfg.max_iter - s.iters));
+    K = max(K, min((cfg.hard_x10 * K) / 10, cfg.max_iter - s.iters));
     seg_end = K;
   }
   __syncthreads();

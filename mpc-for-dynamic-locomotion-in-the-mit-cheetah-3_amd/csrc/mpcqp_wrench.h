@@ -927,7 +927,7 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
     }
     rho = fminf(rho * ratio, ADAPT_RHO_MAX);   // ... and a longer block
     hard = 1;
-    K = max(K, min(HARD_ITER_FACTOR * K, cfg.max_iter - __builtin_amdgcn_readfirstlane(s.iters)));
+    K = max(K, min((cfg.hard_x10 * K) / 10, cfg.max_iter - __builtin_amdgcn_readfirstlane(s.iters)));
     seg_end = K;
   }
   if (fresh_tid<NW>(tid0) == 0) { s.rho = rho; s.iters += K; s.hard |= hard; }
@@ -1031,7 +1031,7 @@ __device__ __forceinline__ unsigned w_aset_hash(SmemW<TV, N>& s, const int tid) 
 template <typename TV, typename TP, int N>
 __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tabs, const TP* __restrict__ kinvT, const int tid0,
                                               const int budget, const bool last, const int trace_tag, const int incr_legs,
-                                              const int patience, const int cheap_steps, const int cheap_legs) {
+                                              const int patience, const int cheap_steps, const int cheap_legs, const int last_patience) {
   constexpr int NL = WG<N>::NL, NW = WG<N>::NW, G = WG<N>::G;
   constexpr int STG = 2 * 21 + 1;   // staging record of a changed leg-stage in s.E: removed | added {A[3][6], weight[3]}, stage index
   static_assert(STG * MPCQP_W_INCR_LEGS <= N * 36, "the staging records share the bytes of E");
@@ -1262,6 +1262,7 @@ __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tab
           if (incr && nupd <= cheap_legs && cheap_used < cheap_steps) ++cheap_used;
           else { done = true; break; }   // uniform
         }
+        if (last && last_patience > 0 && nstall >= last_patience) { done = true; break; }   // uniform
       }
       if (done) break;
       if (!incr) break;   // rebuild for the new active set (outer loop)
@@ -1469,7 +1470,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
 #else
       const int trace_tag = -1;
 #endif
-      if (budget > 0) ok = __builtin_amdgcn_readfirstlane(w_polish_round<TV, TP, N>(s, tabs, kinvP, tid0, budget, last, trace_tag, cfg.incr_legs, cfg.patience, cfg.cheap_steps, cfg.cheap_legs));
+      if (budget > 0) ok = __builtin_amdgcn_readfirstlane(w_polish_round<TV, TP, N>(s, tabs, kinvP, tid0, budget, last, trace_tag, cfg.incr_legs, cfg.patience, cfg.cheap_steps, cfg.cheap_legs, (kind == R_ADMM) ? cfg.last_patience : 0));
       if (ok == 1 && s.alpha > s.alpha_target) {   // next continuation level, from this optimum and its multipliers
         const int tid = fresh_tid<NW>(tid0);
         for (int i = tid; i < n; i += NT) s.ua[i] = s.uv[i];            // the last accepted answer and its multipliers (the ADMM

@@ -9,12 +9,12 @@ allg = ("trot", "pronk", "amble", "gallop")
 seeds = (20250809, 1, 2, 3, 4, 5, 6)
 batches = {sd: mpcqp.synth.make_batch(4096, 10, 0.03, sd, allg, (0.3, 0.5, 0.7, 1.0)) for sd in seeds}
 big = mpcqp.synth.config4(65536)
-combos = [(1, 4, -1, 3), (1, 4, 2, 2), (1, 4, 4, 2), (1, 4, 3, 3), (1, 4, 6, 3), (1, 6, 6, 3), (1, 4, 4, 4), (1, 6, 6, 5)]   # patience, polish_max, cheap steps, cheap legs
+combos = [(0, 400), (2, 400), (3, 400), (4, 400), (0, 500), (3, 500), (0, 340), (3, 340)]   # last-round patience (0: unlimited), max_iter
 if len(sys.argv) > 1:
-    combos = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
-for pat, pmax, cheap, clegs in combos:
-    sol = mpcqp.MPCBatch(N=10, precision="mixed", polish_patience=pat, polish_max=pmax, polish_cheap_steps=cheap, polish_cheap_legs=clegs, flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)
-    line = f"patience {pat} polish_max {pmax} cheap {cheap} legs<={clegs}:"
+    combos = [tuple(float(x) for x in a.split(",")) for a in sys.argv[1:]]
+for lp, mi in combos:
+    sol = mpcqp.MPCBatch(N=10, precision="mixed", polish_last_patience=lp, max_iter=mi, flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)
+    line = f"last-round patience {lp} max_iter {mi}:"
     rates = []
     for sd in seeds:
         dev = sol.upload(batches[sd])

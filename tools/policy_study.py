@@ -12,7 +12,7 @@ sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "oracle"))
 import mpcqp            # noqa: E402
 import qp_spec as S     # noqa: E402
 
-US_ITER, US_SWEEP32, US_SWEEP64, US_STEP = 0.40, 12.0, 19.0, 4.0
+US_ITER, US_SWEEP32, US_SWEEP64, US_STEP, US_LEG = 0.40, 12.0, 19.0, 4.0, 3.7   # (a changed leg-stage: up to six rank-one updates)
 
 
 class QP:
@@ -87,11 +87,11 @@ class QP:
 
 
 def solve(qp, pol):
-    """One QP under a policy dict -> (solved, iters, sweeps32, rebuilds64, steps, rounds)."""
+    """One QP under a policy dict -> (solved, iters, sweeps32, rebuilds64, steps, rounds, updated leg-stages)."""
     n = len(qp.g)
     u, z, y = np.zeros(n), np.zeros(5 * qp.nl), np.zeros(5 * qp.nl)
     rho = pol.get("rho0", 1.0)
-    iters = sw32 = sw64 = steps = 0
+    iters = sw32 = sw64 = steps = legs = 0
     hard = False
     for rnd in range(pol.get("max_rounds", 12)):
         if iters >= pol["max_iter"]:
@@ -103,7 +103,7 @@ def solve(qp, pol):
             rt, _, _ = qp.ratio(u, z, y)
             if rt > pol.get("adapt_thr", 6.0):
                 rho = min(rho * rt, pol.get("rho_max", 30.0)); hard = True
-                K = max(K, min(2 * K, pol["max_iter"] - iters))
+                K = max(K, min(int(pol.get("hard_factor", 2) * K), pol["max_iter"] - iters))
                 u, z, y, Minv = qp.admm(u, z, y, rho, K - 25); sw32 += 1
             else:
                 u, z, y, _ = qp.admm(u, z, y, rho, K - 25, Minv=Minv)
@@ -111,7 +111,7 @@ def solve(qp, pol):
             u, z, y, _ = qp.admm(u, z, y, rho, K); sw32 += 1
         iters += K
         # polish round
-        budget = (2 if hard else 1) * pol["polish_max"]
+        budget = (pol.get("hard_polish", 2) if hard else 1) * pol["polish_max"]
         last = iters >= pol["max_iter"]
         pu, py = u.copy(), y.copy()
         vprev = vprev2 = np.inf
@@ -129,7 +129,7 @@ def solve(qp, pol):
             if ps == 0 or not incr:
                 sw64 += 1; in_row = 0
             if ok:
-                return True, iters, sw32, sw64, steps, rnd + 1
+                return True, iters, sw32, sw64, steps, rnd + 1, legs
             v = pv + dv / max(qp.gmax, 1.0) * 100.0
             one_sided = min(pv, dv) <= 1e-9
             stalled = not (v < 0.5 * vprev)
@@ -141,10 +141,10 @@ def solve(qp, pol):
             new = qp.rule(pu, py)
             nchg = int((new != aset).any(axis=1).sum())
             incr = in_row < 12 and nchg <= 8
-            if incr: in_row += 1
+            if incr: in_row += 1; legs += nchg
             aset = new
             if nstall >= pol["patience"] and not last:
-                if incr and cheap_used < pol.get("cheap", 0):
+                if incr and nchg <= pol.get("cheap_legs", 8) and cheap_used < pol.get("cheap", 0):
                     cheap_used += 1
                 else:
                     break
@@ -162,12 +162,12 @@ def solve(qp, pol):
         elif mode == "damped":
             if np.isfinite(rt) and (rt > 2 or rt < 0.5):
                 rho = min(max(rho * np.sqrt(rt), 1e-4), 1e4)
-    return False, iters, sw32, sw64, steps, pol.get("max_rounds", 12)
+    return False, iters, sw32, sw64, steps, pol.get("max_rounds", 12), legs
 
 
 def cost(res):
-    ok, it, s32, s64, st, rn = res
-    return it * US_ITER + s32 * US_SWEEP32 + s64 * US_SWEEP64 + st * US_STEP
+    ok, it, s32, s64, st, rn, lg = res
+    return it * US_ITER + s32 * US_SWEEP32 + s64 * US_SWEEP64 + st * US_STEP + lg * US_LEG
 
 
 def main():
@@ -192,17 +192,20 @@ def main():
         idx_e = np.where(~((gid == 2) & (mu <= 0.5)))[0][: n_easy // 3]
         easy += [QP(b, i, cfg) for i in idx_e]
     base = dict(first_block=70, block=100, max_iter=400, polish_max=4, patience=1, cheap=0, adapt="osqp")
+    r3 = {**base, "cheap": 3, "cheap_legs": 3}
     policies = {
         "engine (r02)": base,
-        "patience 2": {**base, "patience": 2},
-        "cheap 4": {**base, "cheap": 4},
-        "adapt up_only": {**base, "adapt": "up_only"},
-        "adapt keep": {**base, "adapt": "keep"},
-        "adapt damped": {**base, "adapt": "damped"},
-        "rho_max 100": {**base, "rho_max": 100.0},
-        "block 60 after": {**base, "block": 60},
-        "block 50 after, polish 6": {**base, "block": 50, "polish_max": 6},
-        "thr 3": {**base, "adapt_thr": 3.0},
+        "r03: cheap 3 on <= 3 legs": r3,
+        "r03 + hard block x3": {**r3, "hard_factor": 3},
+        "r03 + hard block x1.5": {**r3, "hard_factor": 1.5},
+        "r03 + later blocks 70": {**r3, "block": 70},
+        "r03 + later blocks 140": {**r3, "block": 140},
+        "r03 + rho_max 60": {**r3, "rho_max": 60.0},
+        "r03 + thr 4": {**r3, "adapt_thr": 4.0},
+        "r03 + thr 9": {**r3, "adapt_thr": 9.0},
+        "r03 + cheap 6 on <= 2": {**base, "cheap": 6, "cheap_legs": 2},
+        "r03 + hard polish x3": {**r3, "hard_polish": 3},
+        "r03 + damped adapt": {**r3, "adapt": "damped"},
     }
     for name, pol in policies.items():
         t0 = time.time()
