@@ -164,3 +164,40 @@ def test_reference_horizon_nonfinite_and_ragged_batches(golden):
     ref = eng.solve_batch_host(b30["x0"], b30["r"], b30["contact"], b30["xdes"], b30["mu"])
     ok = o30["status"] == 1
     assert ok.mean() >= 0.95 and rel_err(o30["u"][ok], ref["u"][ok]).max() <= 1e-4
+
+
+def test_stage_engine_zoh_and_other_constants(oracle_solve):
+    """Nothing in the stage-wise engine is tied to Euler or to the Lite3 defaults: exact zero-order hold (theta = 1/2 in Gam) and other
+    mass / inertia / weights / force bounds / alpha at N = 30, against the oracle; and the two discretisations differ (not vacuous)."""
+    b = mpcqp.synth.make_batch(48, 30, 0.02, 77, ("trot", "gallop", "amble"), (0.4, 0.8))
+    kw = dict(m=12.5, Ibody_inv=[1 / 0.4, 1 / 0.9, 1 / 1.3], w=[2e4, 1e4, 3e4, 1e5, 2e5, 3e5, 5e3, 5e3, 1e4, 1e4, 2e4, 3e4, 0.0],
+              alpha=3e-2, f_min=5.0, f_max=150.0)
+    outs = {}
+    for disc in (mpcqp.DISC_EULER, mpcqp.DISC_ZOH):
+        ref = oracle_solve(b, N=30, delta=0.02, disc=disc, **kw)
+        out = gpu_solve(b, 30, 0.02, "mixed", disc=disc, **kw)
+        ok = out["status"] == 1
+        assert ok.mean() >= 0.95, ok.mean()
+        assert rel_err(out["u"], ref["u"])[ok].max() <= 1e-4 and np.abs(out["X"] - ref["X"])[ok].max() <= 1e-4
+        outs[disc] = ref["u"]
+    assert rel_err(outs[mpcqp.DISC_ZOH], outs[mpcqp.DISC_EULER]).max() > 1e-3
+
+
+def test_device_rollout_at_the_reference_horizon():
+    """mpcqp_rollout with the stage-wise engine underneath (N = 60, delta = 0.01, the reference's step durations 10 / 5 ticks): the device
+    loop (expand -> solve -> advance per tick, no host round trips) against the checker's literal loop on the same robots."""
+    from conftest import ORACLE_SO
+    rb = mpcqp.synth.make_rollout_batch(6, N=60, delta=0.01, seed=5, ss=10, ds=5, total_steps=20)
+    olib = mpcqp.Library(ORACLE_SO)
+    T = 6
+    ref = mpcqp.Engine(olib, olib.default_config(N=60, delta=0.01, max_iter=20000, eps_abs=1e-10, eps_rel=1e-10, polish_max=30)).rollout_host(
+        rb["x"], rb["ref"], rb["plan_pos"], rb["plan_feet_id"], rb["plan_meta"], rb["tick"], rb["mu"], T)
+    sol = mpcqp.MPCBatch(N=60, delta=0.01, io_dtype="f64", precision="mixed")
+    f = lambda a, dt=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device="cuda").contiguous()
+    x, rf, tk = f(rb["x"]), f(rb["ref"]), f(rb["tick"], torch.int32)
+    out = sol.rollout(x, rf, f(rb["plan_pos"]), f(rb["plan_feet_id"], torch.uint8), f(rb["plan_meta"], torch.int32), tk, f(rb["mu"]), T)
+    torch.cuda.synchronize()
+    assert np.all(out["solved"].cpu().numpy() == T) and np.all(ref["solved"] == T)
+    F = out["forces"].cpu().numpy()
+    assert np.abs(F - ref["forces"]).max() <= 1e-4 * np.abs(ref["forces"]).max()      # forces of every tick
+    assert np.abs(x.cpu().numpy() - ref["x"]).max() <= 1e-5                            # the states after T ticks
