@@ -187,6 +187,21 @@ def gait_breakdown(solver, N, delta, B, steps=5, precision="mixed"):
         out["reference_horizon_n60_b1024"] = {"qp_per_s": Bn * 2 / (e0.elapsed_time(e1) * 1e-3), "solved_fraction": float(((st == 1) | (st == 2)).mean()),
                                               "note": "N = 60, delta = 0.01, mixed gaits + mu sweep, stage-wise engine (csrc/mpcqp_stage.h)"}
         del s60
+        # ... and ONE robot, the reference's own use (its log: 61.2 solves/s on its CPU, src/main.py:194-202): solve latency of a batch of
+        # one, cold and warm-started from the previous solution (src/mpc.py:270-271), host-synchronised after every solve
+        one = {k: (v[:1] if isinstance(v, np.ndarray) and len(v) == Bn else v) for k, v in b.items()}
+        for tag, kw in (("cold", {}), ("warm", {"warm_start": True})):
+            s1 = mpcqp.MPCBatch(N=60, delta=0.01, device=solver.device.index, io_dtype="f32", precision=precision, **kw)
+            d1 = s1.upload(one)
+            for _ in range(3):
+                o = s1.solve_batch(d1["x0"], d1["r"], d1["contact"], d1["xdes"], d1["mu"]); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                o = s1.solve_batch(d1["x0"], d1["r"], d1["contact"], d1["xdes"], d1["mu"]); torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t0) / 10
+            out["reference_horizon_n60_single_robot_" + tag] = {"solves_per_s": 1.0 / dt1, "ms_per_solve": dt1 * 1e3, "status": int(o["status"][0].item()),
+                                                                "note": "batch of one, wall clock incl. launch and synchronisation"}
+            del s1
     except Exception as e:
         out["reference_horizon_n60_b1024"] = {"error": repr(e)}
     # two independent batches of B in flight: two handles on two HIP streams (a handle serves one stream at a time,

@@ -66,8 +66,8 @@ extern "C" {
                                     active set and falls back to an ADMM block started from the guess.  The engine also keeps,
                                     per batch slot, the multipliers of its previous solve and starts from those when it has
                                     them (slot b of consecutive calls = the same robot).  Same optimum, same
-                                    status / tolerance contract as a cold solve.  Horizon 10 with polish on; horizon 20 and
-                                    the CPU checker accept the flag (horizon 20 uses the guess, the checker starts cold). */
+                                    status / tolerance contract as a cold solve.  Every horizon of the product library (polish on);
+                                    the CPU checker accepts the flag and starts cold. */
 #define MPCQP_FLAG_WARM_SHIFT 16u    /* with WARM_START: the guess is the PREVIOUS control tick's solution, left in u_out unshifted as the
                                         reference leaves it; the engine uses its stage k + 1 for stage k (last stage repeated) */
 #define MPCQP_FLAG_GENERAL_KERNEL 4u /* product library: use the single-launch general kernel even where the fast path applies */

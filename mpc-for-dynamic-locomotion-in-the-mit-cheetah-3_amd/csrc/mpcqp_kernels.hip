@@ -310,14 +310,12 @@ hipError_t launch_stage(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void*
 // spot (a device-wide synchronisation + allocation -- the only ones a solve can make, and only the first time).
 int reserve_workspace(mpcqp_engine* e, int64_t B) {
   if (B <= 0) return MPCQP_OK;
-  if (stage_path_applies(e)) {   // (fixed size: one factor workspace per resident workgroup)
-    if (!e->stage_ws) {
-      const int64_t slots = e->stage_slots > 0 ? e->stage_slots : 256;
-      if (hipMalloc((void**)&e->stage_ws, (size_t)slots * SG_WS_DOUBLES * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); e->stage_ws = nullptr; return MPCQP_ENOMEM; }
-    }
-    return MPCQP_OK;
+  const bool stage = stage_path_applies(e);
+  if (stage && !e->stage_ws) {   // (fixed size: one factor workspace per resident workgroup)
+    const int64_t slots = e->stage_slots > 0 ? e->stage_slots : 256;
+    if (hipMalloc((void**)&e->stage_ws, (size_t)slots * SG_WS_DOUBLES * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); e->stage_ws = nullptr; return MPCQP_ENOMEM; }
   }
-  if (e->order_cap < B) {
+  if (!stage && e->order_cap < B) {
     int* mem = nullptr;
     const int64_t cap = ((B + 1023) / 1024) * 1024;
     if (hipMalloc(&mem, (size_t)(64 + ORDER_BUCKETS * cap) * sizeof(int)) == hipSuccess) {
@@ -645,20 +643,20 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
   const bool wrench = !stage && wrench_path_applies(h), fast = !stage && !wrench && fast_path_applies(h);
   const bool warm = (h->cfg.flags & MPCQP_FLAG_WARM_START) != 0;   // u_out is read as the initial guess first
   if ((stage || wrench || fast) && reserve_workspace(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_solve_batch: workspace allocation failed");
-  float* ys = (warm && (fast || wrench) && B > 0) ? h->dual_mem : nullptr;
+  float* ys = (warm && (fast || wrench || stage) && B > 0) ? h->dual_mem : nullptr;
   const int shift = (h->cfg.flags & MPCQP_FLAG_WARM_SHIFT) ? 1 : 0;
   const bool timing = !(h->cfg.flags & MPCQP_FLAG_NO_TIMING) && !h->quiet;
   if (!h->ev0_set && timing) he = hipEventRecord(h->ev0, st);
   h->ev0_set = false;
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "hipEventRecord", he);
-  if (B > 0 && stage) {   // (cold solves: the stage-wise engine does not read the warm-start guess)
+  if (B > 0 && stage) {
     if (h->cfg.dtype == MPCQP_DTYPE_F64) {
       const FastIn<double> in = {(const double*)x0, (const double*)r, contact, (const double*)xdes, (const double*)mu,
-                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                                 nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const double*)u_out : nullptr, ys, shift};
       he = launch_stage<double>(h, B, in, u_out, X_out, status, iters, res, st);
     } else {
       const FastIn<float> in = {(const float*)x0, (const float*)r, contact, (const float*)xdes, (const float*)mu,
-                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                                nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const float*)u_out : nullptr, ys, shift};
       he = launch_stage<float>(h, B, in, u_out, X_out, status, iters, res, st);
     }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);

@@ -549,6 +549,56 @@ __device__ __forceinline__ float sg_ratio(SmemS& s, const SLeg& Lg, const double
   return sqrtf((q[0] / fmaxf(sp, 1e-12f)) / fmaxf(q[1] / fmaxf(sd, 1e-12f), 1e-30f));
 }
 
+// Warm start (MPCQP_FLAG_WARM_START [+ WARM_SHIFT]; the reference seeds every solve with its previous solution, src/mpc.py:270-271):
+// same contract as w_warm_start of mpcqp_wrench.h.  The lane's leg-stage reads its guess u0 (stage k + shift, last stage repeated) and the
+// engine's record y0 of the previous solve's multipliers; returns 0 no guess | 1 primal guess only | 2 (u0, y0) nearly a KKT point | 3
+// only a neighbour, with the lane's (pu, py) / (ua, za, ya) set to the start of the active-set iteration / of the ADMM block.
+template <typename TIO>
+__device__ __forceinline__ int sg_warm_start(SmemS& s, SLeg& Lg, const TIO* __restrict__ u0, const float* __restrict__ y0, const int shift,
+                                             const int N, const int tid) {
+  const int k = min(tid, 4 * N - 1) >> 2, l = tid & 3, ks = min(k + shift, N - 1);
+  double f[3] = {0, 0, 0}, y[5] = {0, 0, 0, 0, 0};
+  float amax[2] = {0.f, 0.f};
+  if (Lg.leg && Lg.stance) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const double v = (double)u0[ks * 12 + 3 * l + a]; f[a] = isfinite(v) ? v : 0.0; amax[0] = fmaxf(amax[0], fabsf((float)f[a])); }
+    if (y0) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { const float v = y0[(ks * 4 + l) * 5 + i]; y[i] = isfinite(v) ? (double)v : 0.0; amax[1] = fmaxf(amax[1], fabsf((float)y[i])); }
+    }
+  }
+  block_max<2, SG_NW>(amax, s.red, tid);
+  if (!(amax[0] > 0.f)) return 0;                        // uniform: no guess
+  const bool duals = amax[1] > 0.f;
+  double g3[3];
+  sg_grad(s, Lg, f, g3, N, tid);                          // H u0 + g
+  float rs[1] = {0.f};
+  const double mu = s.mu, flo = s.fmin, fhi = s.fmax;
+  const double g[5] = {f[2], f[0] - mu * f[2], f[0] + mu * f[2], f[1] - mu * f[2], f[1] + mu * f[2]};
+  double z[5] = {0, 0, 0, 0, 0};
+  if (Lg.leg && Lg.stance) {
+    const double tb = 1e-3 * fmax(fabs(f[2]), 1.0), tf = 1e-3 * fmax(mu * fabs(f[2]), 1.0);
+    if (!duals) {   // rows that u0 holds with equality get a unit multiplier of the right sign: the first polish step works on u0's own active set
+      y[0] = f[2] >= fhi - tb ? 1.0 : (f[2] <= flo + tb ? -1.0 : 0.0);
+      y[1] = g[1] >= -tf ? 1.0 : 0.0;  y[2] = g[2] <= tf ? -1.0 : 0.0;
+      y[3] = g[3] >= -tf ? 1.0 : 0.0;  y[4] = g[4] <= tf ? -1.0 : 0.0;
+    }
+    z[0] = f[2] < flo ? flo : (f[2] > fhi ? fhi : f[2]);
+    z[1] = g[1] > 0 ? 0.0 : g[1];  z[2] = g[2] < 0 ? 0.0 : g[2];
+    z[3] = g[3] > 0 ? 0.0 : g[3];  z[4] = g[4] < 0 ? 0.0 : g[4];
+    if (duals) {
+      const double rx = g3[0] + (y[1] + y[2]), ry = g3[1] + (y[3] + y[4]), rz = g3[2] + y[0] + mu * (-y[1] + y[2] - y[3] + y[4]);
+      rs[0] = (float)fmax(fmax(fabs(rx), fabs(ry)), fabs(rz));
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { Lg.pu[a] = f[a]; Lg.ua[a] = f[a]; }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { Lg.py[i] = y[i]; Lg.za[i] = z[i]; Lg.ya[i] = duals ? y[i] : 0.0; }
+  block_max<1, SG_NW>(rs, s.red, tid);
+  return !duals ? 1 : (rs[0] <= WARM_KKT_TOL * fmaxf(s.gmax, 1.f) ? 2 : 3);
+}
+
 // One ADMM block (OSQP algorithm 1, scaled duals) from the lane's (ua, za, ya) with penalty s.rho; `adapt`: the single early rho
 // check of a cold solve's first block.  Updates s.rho / s.iters / s.hard and the lane's iterate (ua, za, ya) and polish start (pu, py).
 template <typename TM>
@@ -856,13 +906,17 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
     const int max_iter = cfg.max_iter, polish_max = cfg.polish_max;
     const bool admm_only = !(cfg.flags & MPCQP_FLAG_POLISH);
     int ok = 0;
-    enum { R_ADMM, R_CONT };
-    int kind = R_ADMM, round = 0, cont_retry = 0;
+    int warm = 0;
+    if (in.u_init) warm = sg_warm_start<TIO>(s, Lg, in.u_init + (size_t)b * n, in.y_state ? in.y_state + (size_t)b * (NL * 5) : nullptr, in.shift, N, tid);
+    enum { R_WARM, R_ADMM, R_CONT };
+    const int warm_tries = admm_only ? 0 : (warm == 1 ? WARM_POLISH : (warm == 2 ? 1 : 0));
+    int kind = warm_tries > 0 ? R_WARM : R_ADMM, round = 0, cont_retry = 0;
     double keep_u[3] = {0, 0, 0}, keep_y[5] = {0, 0, 0, 0, 0};   // the last accepted continuation level
     for (;;) {
-      int budget = 2 * polish_max;
+      int budget = kind == R_WARM ? min(warm_tries, polish_max) : 2 * polish_max;
       if (kind == R_ADMM) {
-        sg_admm<TM>(s, cfg, Lg, ws, round == 0 ? 1 : 0, round == 0 ? cfg.first_block : 0, N, tid);
+        // (a warm start from remembered (u, y): a first block 0.6 of the cold one, as in the dense engine)
+        sg_admm<TM>(s, cfg, Lg, ws, round == 0 ? 1 : 0, round == 0 ? (warm >= 2 ? max(1, (6 * (cfg.first_block > 0 ? cfg.first_block : cfg.check_every)) / 10) : cfg.first_block) : 0, N, tid);
         budget = admm_only ? 0 : (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
       }
       const bool last = kind != R_ADMM || s.iters >= max_iter;
@@ -892,6 +946,7 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
         __syncthreads();
         continue;
       }
+      if (kind == R_WARM) { kind = R_ADMM; continue; }
       if (!admm_only && s.iters >= max_iter) break;
       {
         const float ratio = sg_ratio(s, Lg, Lg.ua, Lg.za, Lg.ya, N, tid);
@@ -920,6 +975,10 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
     if (Lg.leg) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) ug[(size_t)b * n + 3 * tid + c] = (TIO)f[c];
+      if (in.y_state) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) in.y_state[(size_t)b * (NL * 5) + 5 * tid + i] = (float)(ok == 1 ? Lg.py[i] : Lg.ya[i]);
+      }
     }
     if (Xg) {
       double g3[3];

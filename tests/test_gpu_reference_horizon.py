@@ -201,3 +201,35 @@ def test_device_rollout_at_the_reference_horizon():
     F = out["forces"].cpu().numpy()
     assert np.abs(F - ref["forces"]).max() <= 1e-4 * np.abs(ref["forces"]).max()      # forces of every tick
     assert np.abs(x.cpu().numpy() - ref["x"]).max() <= 1e-5                            # the states after T ticks
+
+
+def test_reference_horizon_warm_start(golden):
+    """The reference seeds every solve with its previous solution (src/mpc.py:270-271).  On the stage-wise engine: restarting the ten
+    golden N = 60 ticks from their own optimum (and the engine's multiplier record) costs no ADMM block and returns the cold answer; and
+    a tick seeded with the PREVIOUS tick's solution, shifted by the engine (MPCQP_FLAG_WARM_SHIFT), reaches the same optimum as a cold
+    solve with fewer iterations."""
+    q, opt = golden["qp_inputs"], golden["qp_optima"]
+    b = {"x0": q["N60_x0"], "r": q["N60_r"], "contact": q["N60_contact"], "xdes": q["N60_xdes"], "mu": np.full(10, float(q["mu"]))}
+    sol = mpcqp.MPCBatch(N=60, delta=0.01, io_dtype="f64", precision="mixed", warm_start=True)
+    dev = sol.upload(b)
+    o1 = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"]); torch.cuda.synchronize()      # zeros = no guess: cold
+    u1, it1 = o1["u"].cpu().numpy().copy(), o1["iters"].cpu().numpy().copy()
+    o2 = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"]); torch.cuda.synchronize()      # seeded with its own solution
+    u2, it2, st2 = o2["u"].cpu().numpy(), o2["iters"].cpu().numpy(), o2["status"].cpu().numpy()
+    assert np.all(st2 == 1)
+    assert rel_err(u1, opt["N60_a1e-2_u"]).max() <= 1e-4 and rel_err(u2, opt["N60_a1e-2_u"]).max() <= 1e-4
+    assert np.all(it2 % 1000 == 0) and np.all(it1 % 1000 > 0)               # a KKT point as the guess: one polish step, no ADMM block
+    # consecutive ticks of the logged run, the guess one tick old
+    ticks = np.arange(100, 140)
+    run = logged_run_inputs(golden, 60, ticks)
+    cold = gpu_solve(run, 60, 0.01, "mixed")
+    ws = mpcqp.MPCBatch(N=60, delta=0.01, io_dtype="f64", precision="mixed", warm_start=True, warm_shift=True)
+    its = []
+    for i in range(len(ticks)):
+        one = {k: v[i:i + 1] for k, v in run.items()}
+        d = ws.upload(one)
+        o = ws.solve_batch(d["x0"], d["r"], d["contact"], d["xdes"], d["mu"]); torch.cuda.synchronize()              # the buffer holds tick i - 1's solution
+        assert int(o["status"][0]) == 1
+        assert rel_err(o["u"].cpu().numpy(), cold["u"][i:i + 1]).max() <= 1e-4
+        its.append(int(o["iters"][0]) % 1000)
+    assert np.mean(its[1:]) < 0.7 * np.mean(cold["iters"][1:] % 1000), (np.mean(its[1:]), np.mean(cold["iters"][1:] % 1000))

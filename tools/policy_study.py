@@ -148,6 +148,9 @@ def solve(qp, pol):
                     cheap_used += 1
                 else:
                     break
+        if pol.get("restart_from_polish") and np.all(np.isfinite(pu)):   # the next block starts from the last polish candidate
+            lo_, hi_ = np.where(np.isfinite(qp.lo), qp.lo, -1e30), np.where(np.isfinite(qp.hi), qp.hi, 1e30)
+            u, z, y = pu.copy(), np.clip(qp.G @ pu, lo_, hi_), py.copy()
         # rho adaptation for the next round
         rt, rp, rd = qp.ratio(u, z, y)
         mode = pol.get("adapt", "osqp")
@@ -193,7 +196,10 @@ def main():
         easy += [QP(b, i, cfg) for i in idx_e]
     base = dict(first_block=70, block=100, max_iter=400, polish_max=4, patience=1, cheap=0, adapt="osqp")
     r3 = {**base, "cheap": 3, "cheap_legs": 3}
+    r3f = {**r3, "hard_factor": 3}
     policies = {
+        "r03 final": r3f,
+        "r03 final + restart from polish": {**r3f, "restart_from_polish": True},
         "engine (r02)": base,
         "r03: cheap 3 on <= 3 legs": r3,
         "r03 + hard block x3": {**r3, "hard_factor": 3},
