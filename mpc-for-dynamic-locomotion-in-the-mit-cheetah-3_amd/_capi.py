@@ -104,13 +104,13 @@ class Library:
             # (stage-wise engine, any other horizon: an iteration costs two recursions of N steps there and a polish attempt one
             #  factorisation, so shorter blocks pay -- 2 N: 120 at the reference's N = 60, tools/stage_sweep.py: 79.9 k QP/s on the
             #  logged ticks against 29.3 k at 10 N, 38.2 k against 20.3 k on a synthetic mixed batch, 100 % solved at both)
-            cfg.check_every = max(1, 2 * n) if stage else max(1, cfg.check_every * n // 10)
+            cfg.check_every = max(50, 2 * n) if stage else max(1, cfg.check_every * n // 10)
             if "max_iter" not in overrides:
-                cfg.max_iter = max(1, cfg.max_iter * n // 10)
+                cfg.max_iter = max(400 if stage else 1, cfg.max_iter * n // 10)
         # ... and so is the polish budget per round: twice the leg-stages, twice the steps (N = 20, eight batches of 4096: 14 -> 3
         # QPs left at the iteration cap at the same rate, tools/adapt_sweep.py; the steps inside a round update the inverse)
         if n != 10 and "polish_max" not in overrides:
-            cfg.polish_max = max(1, cfg.polish_max * min(n, 20) // 10)
+            cfg.polish_max = max(4, cfg.polish_max * min(n, 20) // 10)
         for k, v in overrides.items():
             if k in ("w", "Ibody_inv"):
                 arr = getattr(cfg, k)

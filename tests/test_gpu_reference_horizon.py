@@ -233,3 +233,17 @@ def test_reference_horizon_warm_start(golden):
         assert rel_err(o["u"].cpu().numpy(), cold["u"][i:i + 1]).max() <= 1e-4
         its.append(int(o["iters"][0]) % 1000)
     assert np.mean(its[1:]) < 0.7 * np.mean(cold["iters"][1:] % 1000), (np.mean(its[1:]), np.mean(cold["iters"][1:] % 1000))
+
+
+@pytest.mark.parametrize("N", [1, 2, 7, 33, 64])
+def test_stage_engine_horizon_edges(oracle_solve, N):
+    """Every horizon the header promises (1..64): the shortest ones, an odd one, and the largest (4 N = 256 leg-stages: every lane of the
+    workgroup owns one), against the oracle; batch sizes around the resident-workgroup count are covered by the 1000-tick test."""
+    b = mpcqp.synth.make_batch(40, N, 0.02, 100 + N, ("trot", "gallop", "amble", "pronk"), (0.5, 1.0))
+    ref = oracle_solve(b, N=N, delta=0.02)
+    out = gpu_solve(b, N, 0.02, "mixed")
+    ok = out["status"] == 1
+    assert ok.mean() >= 0.95, (N, ok.mean())
+    assert rel_err(out["u"], ref["u"])[ok].max() <= 1e-4 and np.abs(out["X"] - ref["X"])[ok].max() <= 1e-4
+    swing = np.repeat(b["contact"] == 0, 3, axis=2).reshape(40, N, 12)
+    assert np.all(out["u"][swing] == 0)
