@@ -242,7 +242,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="QPs per GPU")
-    ap.add_argument("--precision", default="mixed", choices=["f32", "mixed", "f64"])
+    ap.add_argument("--precision", default="mixed", choices=["mixed", "f64"])
     ap.add_argument("--allgather", action="store_true", help="all-gather stage-0 GRFs over RCCL every step")
     ap.add_argument("--distinct-shards", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--same-shards", action="store_true", help="N > 1, weak mode: every rank solves the configured batch (seed 20250809) instead of its own draw")
@@ -401,7 +401,7 @@ def main():
             "ms_per_step_median": median_ms,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "rank_kernel_ms": {"min": min(rank_ms), "mean": sum(rank_ms) / len(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
-            "dtype": {"f32": "f32", "mixed": "f32 tiles + f64 residuals", "f64": "f64"}[args.precision],
+            "dtype": {"mixed": "f32 tiles + f64 residuals", "f64": "f64"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "configs[2]: batch=4096/GPU mixed gaits (trot/pronk/amble/gallop) + mu sweep, horizon=10, "
                                    "dt=0.03, Lite3 constants, alpha=1e-2, euler", "batch_per_gpu": B, "global_batch": total_qps,
@@ -415,7 +415,7 @@ def main():
                          "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "mpcqp_wrench_solve<double,float,double> (one launch per solve_batch, after a 5 us ordering pre-pass; both inside kernel_ms)" if args.precision == "mixed"
-                         else "mpcqp_fast_solve<float,float>" if args.precision == "f32" else "mpcqp_wrench_solve<double,double,double>",
+                         else "mpcqp_wrench_solve<double,double,double>",
                          "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_qp": flops,
                          "achieved_is": "notional: ALGORITHMIC flops of the condensed formulation (SURVEY 8d) over the measured duration; the engine executes fewer (see `executed`)",

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_VERSION 0x00010100 /* 1.1.0: horizons up to 64 (stage-wise engine), tuning fields in MpcQpConfig */
+#define MPCQP_VERSION 0x00010200 /* 1.2.0: round-1 kernels retired (two engines: wrench-space, stage-wise); 1.1.0: horizons up to 64, tuning fields */
 
 /* return codes */
 #define MPCQP_OK 0
@@ -52,8 +52,8 @@ extern "C" {
 #define MPCQP_DTYPE_F64 1
 
 /* arithmetic of the engine (product library; the oracle is always all-f64) */
-#define MPCQP_PREC_F32 0   /* matrix tiles and vectors in f32 (GRFs within 2e-2; at N = 20 that band does not hold and the product
-                              library serves the request with MIXED) */
+#define MPCQP_PREC_F32 0   /* (the all-f32 arithmetic of the round-1 kernels, GRFs within 2e-2: retired -- the product library serves the
+                              request with MIXED, which is no slower and meets the 1e-4 band) */
 #define MPCQP_PREC_MIXED 1 /* matrix tiles f32; structured residuals, refinement and duals in f64 */
 #define MPCQP_PREC_F64 2   /* everything f64 */
 
@@ -70,16 +70,16 @@ extern "C" {
                                     the CPU checker accepts the flag and starts cold. */
 #define MPCQP_FLAG_WARM_SHIFT 16u    /* with WARM_START: the guess is the PREVIOUS control tick's solution, left in u_out unshifted as the
                                         reference leaves it; the engine uses its stage k + 1 for stage k (last stage repeated) */
-#define MPCQP_FLAG_GENERAL_KERNEL 4u /* product library: use the single-launch general kernel even where the fast path applies */
-#define MPCQP_FLAG_TILE_KERNEL 32u    /* product library: use the round-1 120 x 120 register-tile kernel (mpcqp_fast.h) even where the
-                                        wrench-space engine (mpcqp_wrench.h) applies; for A/B measurements */
+#define MPCQP_FLAG_GENERAL_KERNEL 4u /* accepted and ignored: selected the round-1 general kernel, retired in 1.2 (its figures: profiles/r01_*) */
+#define MPCQP_FLAG_TILE_KERNEL 32u   /* accepted and ignored: selected the round-1 120 x 120 register-tile kernel, retired in 1.2 */
 #define MPCQP_FLAG_NATURAL_ORDER 8u  /* product library: one workgroup per QP in batch order.  By default a batch that
                                         oversubscribes the device (more than 2 QPs per CU) is solved by resident workgroups that pull
                                         QPs dearest-expected-first from a queue (a pre-pass ranks the support patterns by
                                         friction demand): same per-QP results, shorter launch */
 
 #define MPCQP_FLAG_STAGE_KERNEL 128u  /* product library: use the stage-wise (Riccati) engine (mpcqp_stage.h) at horizons 10 and 20 as well, where the
-                                        dense wrench-space engine is the default; other horizons (up to 64) always use it */
+                                        dense wrench-space engine is the default; other horizons (up to 64), and cost weights whose two
+                                        horizontal angular-velocity entries differ (w[6] != w[7]), always use it */
 #define MPCQP_FLAG_NO_TIMING 64u     /* product library: do not record the HIP event pair around each solve that mpcqp_last_kernel_ms()
                                         reads (two extra packets on the stream per call, ~15 us of a 0.46 ms solve of 4096 QPs);
                                         mpcqp_last_kernel_ms() then returns MPCQP_EINVAL */

@@ -1,4 +1,4 @@
-// mpcqp_device.h -- device-side helpers shared by the general and the fast-path kernels (gfx950, wave64).
+// mpcqp_device.h -- device-side helpers shared by the wrench-space and the stage-wise engine (gfx950, wave64).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -52,13 +52,6 @@ struct DevCfg {
   int hard_x10;         // wrench engine: first-block length of a QP the early rho check flags, in tenths of the normal first block
   int last_patience;    // wrench engine: patience of a round that nothing follows (0: unlimited)
   int refine_admm;      // all-fp64 ADMM without polish at tolerances below 1e-6: one refinement step per linear solve
-};
-
-// Problem constants staged in LDS in the vector precision (keeps ~100 scalar registers free).
-template <typename TV>
-struct CfgS {
-  TV delta, theta, alpha, inv_m, fmin, fmax;
-  TV Ib[3], w[12], sw[12];
 };
 
 // Sum over the 8 lanes of a leg group with DPP lane moves (no LDS crossbar): quad butterfly, then half-row mirror.
@@ -115,120 +108,6 @@ __device__ __forceinline__ void block_max(float (&v)[Q], float* red, int tid) {
     v[q] = m;
   }
   __syncthreads();
-}
-
-// Gradient of the reference cost (src/mpc.py:121-134, + alpha |u|^2) at s.uv, by rollout + adjoint.
-// Needs s.uv visible (barrier before the call).  Leaves s.gv, s.Xs (states), s.es (weighted errors); ends
-// with a barrier.  Closed forms: for Euler (theta = 0) / ZOH (theta = 1/2)
-//   omega_k = omega_0 + d sum_{j<k} tau_j                      v_k = v_0 + d sum_{j<k} a_j + k d g e_z
-//   Theta_k = Theta_0 + k d Rz omega_0 + d^2 sum_{j<k} (k-1-j+theta) Rz tau_j
-//   p_k     = p_0 + k d v_0 + d^2 sum_{j<k} (k-1-j+theta) a_j + d^2 g (k(k-1)/2 + theta k) e_z
-// with tau_j = sum_i tt_i u_i, a_j = sum_i cm_i u_i e_axis(i) over the variables of stage j
-// (src/mpc.py:86-117 restated; tt_i = I_hat_inv (r x e_axis), src/mpc.py:78,98-107).
-// Every phase is ONE branch-free instruction stream for all lanes: the lane's role only selects array bases, offsets
-// and coefficients, and the (j < k) / (k > j) limits of the prefix sums are zero coefficients, not predicated loads
-// (role branches + predicated iterations serialised one LDS latency per term: 7.9 k cycles per call, 13 % of a solve).
-template <typename SM, typename TV, int N>
-__device__ __forceinline__ void struct_grad(SM& s, int tid) {
-  static_assert(N % 5 == 0, "prefix sums are chunked by five stages");
-  constexpr int n = 12 * N;
-  const TV d = s.cf.delta, th = s.cf.theta;
-  if (tid < N * 9) {   // per-stage wrench: tau_j (q < 3), Rz tau_j (3..5), mass-scaled force sum a_j (6..8)
-    const int j = tid / 9, q = tid % 9, dd = q % 3;
-    // (one LDS base + a per-role element offset: selecting between the member arrays by pointer would lose the LDS
-    //  address space and turn the reads into flat loads)
-    const int roff = q < 3 ? 0 : (q < 6 ? (int)(s.ttr - s.tt) : (int)(s.cm - s.tt));
-    const int stride = q < 6 ? 3 : 1, off = roff + (q < 6 ? dd : 0);
-    TV acc = 0;
-#pragma unroll
-    for (int i0 = 0; i0 < 12; i0 += 4) {   // four terms' loads in flight at a time (the caller's register tile is live)
-      asm volatile("" ::: "memory");
-      TV a[4], u[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = s.tt[(12 * j + i0 + i) * stride + off]; u[i] = s.uv[12 * j + i0 + i]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const TV m = (q < 6 || (i0 + i) % 3 == dd) ? (TV)1 : (TV)0;   // a_j only collects its own axis
-        acc += (a[i] * m) * u[i];
-      }
-    }
-    s.wr[tid] = acc;
-  }
-  __syncthreads();
-  if (tid < N * 12) {   // states X_k, k = 1..N: prefix sums of the wrench, weighted by (k-1-j+theta) for angles / position
-    const int k = tid / 12 + 1, c = tid % 12, dd = c % 3;
-    const TV g = s.x0[12];
-    const bool weighted = c < 6;
-    const int off = c < 3 ? 3 + dd : (c < 6 ? 6 + dd : (c < 9 ? dd : 6 + dd));
-    TV acc = 0;
-#pragma unroll
-    for (int j0 = 0; j0 < N; j0 += 5) {
-      asm volatile("" ::: "memory");
-      TV w[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) w[j] = s.wr[(j0 + j) * 9 + off];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const TV cf = (j0 + j < k) ? (weighted ? (TV)(k - 1 - j0 - j) + th : (TV)1) : (TV)0;
-        acc += cf * w[j];
-      }
-    }
-    TV val;
-    if (c < 3) val = s.x0[dd] + (TV)k * d * s.rzw0[dd] + d * d * acc;
-    else if (c < 6) {
-      val = s.x0[3 + dd] + (TV)k * d * s.x0[9 + dd] + d * d * acc;
-      if (dd == 2) val += d * d * g * ((TV)(k * (k - 1)) * (TV)0.5 + th * (TV)k);
-    } else if (c < 9) val = s.x0[6 + dd] + d * acc;
-    else {
-      val = s.x0[9 + dd] + d * acc;
-      if (dd == 2) val += (TV)k * d * g;
-    }
-    s.Xs[k * 12 + c] = val;
-    s.es[k * 12 + c] = s.cf.w[c] * (val - s.xd[k * 13 + c]);
-  }
-  __syncthreads();
-  if (tid < N * 9) {   // adjoint of the prefix sums: out = c1 S1 + c2 S2, S1 plain / S2 weighted suffix sums of the errors
-    const int j = tid / 9, q = tid % 9, dd = q % 3;
-    const int off1 = q < 3 ? 6 + dd : 9 + dd, off2 = q < 6 ? dd : 3 + dd;
-    const TV c1 = (q >= 3 && q < 6) ? (TV)0 : (TV)2 * d, c2 = q < 3 ? (TV)0 : (TV)2 * d * d;
-    TV a1 = 0, a2 = 0;
-#pragma unroll
-    for (int k0 = 1; k0 <= N; k0 += 5) {
-      asm volatile("" ::: "memory");
-      TV e1[5], e2[5];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) { e1[k] = s.es[(k0 + k) * 12 + off1]; e2[k] = s.es[(k0 + k) * 12 + off2]; }
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const TV on = (k0 + k > j) ? (TV)1 : (TV)0;
-        a1 += on * e1[k];
-        a2 += (on * ((TV)(k0 + k - 1 - j) + th)) * e2[k];
-      }
-    }
-    s.adj[tid] = c1 * a1 + c2 * a2;
-  }
-  __syncthreads();
-  if (tid < n) {
-    const int j = tid / 12, a = tid % 3;
-    TV gsum = (TV)2 * s.cf.alpha * s.uv[tid];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) gsum += s.tt[tid * 3 + q] * s.adj[j * 9 + q] + s.ttr[tid * 3 + q] * s.adj[j * 9 + 3 + q];
-    gsum += s.cm[tid] * s.adj[j * 9 + 6 + a];
-    s.gv[tid] = gsum;
-  }
-  __syncthreads();
-}
-
-// Weighted 12-vector [P(6) | Q(6)] of force variable i (axis a): H_ii' = 2 (c1 P.P' + c0 Q.Q').
-template <typename SM, typename TV>
-__device__ __forceinline__ void var_pq(const SM& s, int i, int a, TV (&o)[12]) {
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    o[q] = s.cf.sw[q] * s.ttr[i * 3 + q];
-    o[3 + q] = (q == a) ? s.cf.sw[3 + q] * s.cm[i] : (TV)0;
-    o[6 + q] = s.cf.sw[6 + q] * s.tt[i * 3 + q];
-    o[9 + q] = (q == a) ? s.cf.sw[9 + q] * s.cm[i] : (TV)0;
-  }
 }
 
 }  // namespace

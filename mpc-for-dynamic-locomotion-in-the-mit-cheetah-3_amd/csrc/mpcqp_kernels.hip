@@ -3,19 +3,14 @@
 // Replaces, for a batch of B independent robots, the solve the reference performs once per control tick:
 // CasADi Opti('conic') -> OSQP on the QP of src/mpc.py:58-173, filled at src/mpc.py:242-255, solved at :258.
 //
-// This translation unit is the C-ABI of include/mpcqp.h and the dispatch between three device implementations:
+// This translation unit is the C-ABI of include/mpcqp.h and the dispatch between two device implementations of one algorithm:
 //   mpcqp_wrench.h   the engine: wrench-space (Woodbury) form, H = 2 alpha I + T'KT with a 6N x 6N system, one QP per wave
 //                    (horizon 10) or per four waves (horizon 20), fp32 or fp64 ADMM, fp64 active-set polish, ADMM-only mode
 //   mpcqp_stage.h    stage-wise (Riccati) form of the same engine for any other horizon up to 64 -- the reference's own N = 60
-//   mpcqp_fast.h     round-1 horizon-10 kernel (120 x 120 closed-form register tiles over three waves): all-fp32 arithmetic,
-//                    weights the wrench form does not admit, MPCQP_FLAG_TILE_KERNEL
-//   mpcqp_general.h  round-1 single-launch state machine: alpha = 0 with polish requested, horizon 20 in fp32
-//   mpcqp_device.h   what they share: DPP reductions, the O(N) rollout + adjoint gradient of the round-1 kernels
+//   mpcqp_common.h   what they share: operator-tuple descriptor, policy constants, the dispatch-order pre-pass;  mpcqp_device.h: DPP helpers
 // plus the element-wise kernels around the solve: gait-descriptor expansion, closed-loop roll-out (expand / advance), torque map.
 // DESIGN.md has the derivations.
 
-#include "mpcqp_general.h"
-#include "mpcqp_fast.h"
 #include "mpcqp_wrench.h"
 #include "mpcqp_stage.h"
 
@@ -170,7 +165,6 @@ mpcqp_rollout_advance_kernel(TIO* __restrict__ x, TIO* __restrict__ ref, const R
 struct mpcqp_engine {
   MpcQpConfig cfg;
   DevCfg dev;
-  double* ctab = nullptr;   // [2][N][N] coefficient tables on the device
   DevCfg* dcfg = nullptr;   // device copy of `dev`
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int* order_mem = nullptr;   // dispatch order: [2 x 32 header ints (class counters, queue head), alternating between calls | ORDER_BUCKETS x order_cap indices]
@@ -209,16 +203,6 @@ int fail(mpcqp_engine* e, int code, const char* what, hipError_t he = hipSuccess
   return code;
 }
 
-template <typename T, typename TV, typename TIO, int N>
-hipError_t launch(const mpcqp_engine* e, int64_t B, const void* x0, const void* r, const uint8_t* contact,
-                  const void* xdes, const void* mu, void* u, void* X, int32_t* status, int32_t* iters, float* res,
-                  hipStream_t st) {
-  hipLaunchKernelGGL((mpcqp_solve_kernel<T, TV, TIO, N>), dim3((unsigned)B), dim3(Geo<N>::NT), 0, st, e->dcfg, e->ctab,
-                     (const TIO*)x0, (const TIO*)r, contact, (const TIO*)xdes, (const TIO*)mu, (TIO*)u, (TIO*)X,
-                     status, iters, res);
-  return hipGetLastError();
-}
-
 #ifndef MPCQP_DEBUG_DYN_LDS
 #define MPCQP_DEBUG_DYN_LDS 0   // occupancy experiments only: extra dynamic LDS per workgroup
 #endif
@@ -231,27 +215,6 @@ static OrderBuf next_order_buf(mpcqp_engine* e) {
   ob.list = e->order_mem + 64; ob.cap = e->order_cap;
   e->order_phase ^= 1;
   return ob;
-}
-
-// Fast path (mpcqp_fast.h): one launch, one QP per workgroup, phases as separately register-allocated device functions.
-template <typename TIO>
-hipError_t launch_fast(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void* u, void* X, int32_t* st, int32_t* it,
-                       float* res, hipStream_t s) {
-  dim3 grid((unsigned)B);
-  OrderBuf ob = {nullptr, nullptr, 0, nullptr, nullptr};
-  // dispatch order (mpcqp_fast.h): worth a pre-pass as soon as the batch oversubscribes the workgroup slots
-  if (!(e->cfg.flags & MPCQP_FLAG_NATURAL_ORDER) && e->slots > 0 && B > (int64_t)e->slots && e->order_cap >= B) {
-    ob = next_order_buf(e);
-    hipLaunchKernelGGL((mpcqp_order_kernel<TIO>), dim3((unsigned)((B + 63) / 64)), dim3(1024), 0, s, in, (int)B, ob);
-    grid = dim3((unsigned)(B < e->slots ? B : e->slots));   // queued form: resident workgroups pull QPs
-  }
-  if (e->cfg.precision == MPCQP_PREC_MIXED)
-    hipLaunchKernelGGL((mpcqp_fast_solve<double, TIO>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
-                       st, it, res, ob, (int)B);
-  else
-    hipLaunchKernelGGL((mpcqp_fast_solve<float, TIO>), grid, dim3(FG::NT), MPCQP_DEBUG_DYN_LDS, s, e->dcfg, e->ctab, in, (TIO*)u, (TIO*)X,
-                       st, it, res, ob, (int)B);
-  return hipGetLastError();
 }
 
 // Wrench-space engine (mpcqp_wrench.h).  Horizon 10: one QP per wave, 2 waves per SIMD = 8 resident workgroups per CU, queued
@@ -362,34 +325,15 @@ struct DeviceGuard {
   ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
-bool stage_path_applies(const mpcqp_engine* h) {
-  if (!h->form_ok || (h->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL))) return false;
-  return (h->cfg.N != 10 && h->cfg.N != 20) || (h->cfg.flags & MPCQP_FLAG_STAGE_KERNEL);
-}
-
+// Which of the two engines serves a configuration.  The dense wrench-space engine needs its per-component tables: horizon 10 or 20 and an
+// omega weight that is isotropic in x, y (K block diagonal in the wrench components); everything else -- other horizons, anisotropic
+// omega weights (the recursion carries the 2 x 2 coupled weight), MPCQP_FLAG_STAGE_KERNEL -- runs on the stage-wise engine.
 bool wrench_path_applies(const mpcqp_engine* h) {
-  if (h->cfg.flags & MPCQP_FLAG_STAGE_KERNEL) return false;
   // (any alpha >= 0: a request below 1e-2 -- the reference's own 0.0 included -- is served by continuation, mpcqp_wrench.h)
-  return h->wrench_ok && h->cfg.precision != MPCQP_PREC_F32 && !(h->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL));
+  return h->wrench_ok && !(h->cfg.flags & MPCQP_FLAG_STAGE_KERNEL);
 }
 
-bool fast_path_applies(const mpcqp_engine* h) {
-  return h->cfg.N == 10 && h->cfg.precision != MPCQP_PREC_F64 && (h->cfg.flags & MPCQP_FLAG_POLISH) &&
-         !(h->cfg.flags & MPCQP_FLAG_GENERAL_KERNEL) && h->cfg.alpha > 0.0;
-}
-
-template <typename TIO, int N>
-hipError_t launch_prec(const mpcqp_engine* e, int64_t B, const void* x0, const void* r, const uint8_t* c,
-                       const void* xd, const void* mu, void* u, void* X, int32_t* st, int32_t* it, float* res,
-                       hipStream_t s) {
-  switch (e->cfg.precision) {
-    case MPCQP_PREC_F32: return launch<float, float, TIO, N>(e, B, x0, r, c, xd, mu, u, X, st, it, res, s);
-    case MPCQP_PREC_MIXED: return launch<float, double, TIO, N>(e, B, x0, r, c, xd, mu, u, X, st, it, res, s);
-    default:
-      if constexpr (N == 10) return launch<double, double, TIO, N>(e, B, x0, r, c, xd, mu, u, X, st, it, res, s);
-      else return hipErrorInvalidValue;
-  }
-}
+bool stage_path_applies(const mpcqp_engine* h) { return h->form_ok && !wrench_path_applies(h); }
 
 }  // namespace
 
@@ -448,7 +392,6 @@ static bool build_wrench_tables(mpcqp_engine* e, const double* tab /* c0 | c1 */
 }
 
 static void free_engine(mpcqp_engine* h) {
-  if (h->ctab) (void)hipFree(h->ctab);
   if (h->dcfg) (void)hipFree(h->dcfg);
   if (h->order_mem) (void)hipFree(h->order_mem);
   if (h->dual_mem) (void)hipFree(h->dual_mem);
@@ -515,7 +458,7 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return reject(MPCQP_ENODEV);
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return reject(MPCQP_ENODEV);  // gfx950 code objects only
-  e->slots = 2 * prop.multiProcessorCount;   // the tile kernel's 256-VGPR, 3-wave workgroups: two per CU
+  e->slots = 2 * prop.multiProcessorCount;   // the horizon-20 kernel's 256-VGPR, 4-wave workgroups: two per CU (horizon 10: four times that)
   DeviceGuard guard(cfg->device);            // the caller's current device is restored on return
   if (guard.err != hipSuccess) return reject(MPCQP_EHIP);
 
@@ -569,13 +512,12 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
       for (int k = mx + 1; k <= N; ++k) sacc += ((double)(k - 1 - a) + th) * ((double)(k - 1 - bq) + th);
       tab[N * N + a * N + bq] = dl * dl * dl * dl * sacc;
     }
-  hipError_t he = hipMalloc((void**)&e->ctab, sizeof(double) * 2 * N * N);
-  if (he == hipSuccess) he = hipMemcpy(e->ctab, tab, sizeof(double) * 2 * N * N, hipMemcpyHostToDevice);
-  e->form_ok = cfg->w[6] == cfg->w[7];
+  hipError_t he = hipSuccess;
+  e->form_ok = true;   // both engines need positive velocity weights (K positive definite / Pi_N > 0)
   for (int i = 6; i < 12; ++i) e->form_ok = e->form_ok && cfg->w[i] > 0;
   if (he == hipSuccess && (N == 10 || N == 20)) e->wrench_ok = N == 10 ? build_wrench_tables<10>(e, tab) : build_wrench_tables<20>(e, tab);
   // Other horizons (the reference's committed N = 60, src/main.py:37) and MPCQP_FLAG_STAGE_KERNEL: the stage-wise engine.
-  if (he == hipSuccess && (N != 10 && N != 20) && !e->form_ok) { delete[] tab; return reject(MPCQP_EINVAL); }
+  if (he == hipSuccess && !e->form_ok) { delete[] tab; return reject(MPCQP_EINVAL); }   // (a zero velocity weight: no engine serves it)
   if (he == hipSuccess && stage_path_applies(e)) {
     // The recursion's solve carries ~10 x the error of the dense fp64 sweep (tools/stage_proto.py), and the Woodbury form amplifies it
     // by 1 / (2 alpha): the alpha = 0 continuation of this engine ends at 2e-5 (objective within 2e-7, states within 9e-5 of the
@@ -594,13 +536,9 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
     if (oe != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
     e->stage_slots = per_cu * prop.multiProcessorCount;
   }
-  // All-fp32 arithmetic does not hold its 2e-2 band at horizon 20 (forces off by up to 9e-2 on 3 % of config 5, measured): such a
-  // request is served with the MIXED arithmetic (fp32 tiles, fp64 residuals / polish) wherever the wrench-space engine applies.
-  if (he == hipSuccess && N != 10 && e->cfg.precision == MPCQP_PREC_F32 && (e->wrench_ok || stage_path_applies(e)) &&
-      !(e->cfg.flags & (MPCQP_FLAG_GENERAL_KERNEL | MPCQP_FLAG_TILE_KERNEL)))
-    e->cfg.precision = MPCQP_PREC_MIXED;
-  // (all-fp64 arithmetic at horizon 20 exists only in the wrench-space and stage-wise engines)
-  if (he == hipSuccess && cfg->precision == MPCQP_PREC_F64 && N != 10 && !wrench_path_applies(e) && !stage_path_applies(e)) { delete[] tab; return reject(MPCQP_EINVAL); }
+  // MPCQP_PREC_F32 (everything fp32) was the arithmetic of the round-1 kernels; it held a 2e-2 band at horizon 10 and none at 20.  The
+  // request is served with MIXED (fp32 tiles / chains, fp64 residuals and polish), which is no slower and meets the 1e-4 band.
+  if (e->cfg.precision == MPCQP_PREC_F32) e->cfg.precision = MPCQP_PREC_MIXED;
   delete[] tab;
   if (he == hipSuccess) he = hipMalloc((void**)&e->dcfg, sizeof(DevCfg));
   if (he == hipSuccess) he = hipMemcpy(e->dcfg, &e->dev, sizeof(DevCfg), hipMemcpyHostToDevice);
@@ -639,11 +577,10 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
   if (guard.err != hipSuccess) return fail(h, MPCQP_EHIP, "hipSetDevice", guard.err);
   hipStream_t st = (hipStream_t)stream;
   hipError_t he = hipSuccess;
-  const bool stage = stage_path_applies(h);
-  const bool wrench = !stage && wrench_path_applies(h), fast = !stage && !wrench && fast_path_applies(h);
+  const bool stage = stage_path_applies(h), wrench = !stage;
   const bool warm = (h->cfg.flags & MPCQP_FLAG_WARM_START) != 0;   // u_out is read as the initial guess first
-  if ((stage || wrench || fast) && reserve_workspace(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_solve_batch: workspace allocation failed");
-  float* ys = (warm && (fast || wrench || stage) && B > 0) ? h->dual_mem : nullptr;
+  if (reserve_workspace(h, B) != MPCQP_OK) return fail(h, MPCQP_ENOMEM, "mpcqp_solve_batch: workspace allocation failed");
+  float* ys = (warm && B > 0) ? h->dual_mem : nullptr;
   const int shift = (h->cfg.flags & MPCQP_FLAG_WARM_SHIFT) ? 1 : 0;
   const bool timing = !(h->cfg.flags & MPCQP_FLAG_NO_TIMING) && !h->quiet;
   if (!h->ev0_set && timing) he = hipEventRecord(h->ev0, st);
@@ -660,27 +597,16 @@ int mpcqp_solve_batch(mpcqp_handle h, int64_t B, const void* x0, const void* r, 
       he = launch_stage<float>(h, B, in, u_out, X_out, status, iters, res, st);
     }
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
-  } else if (B > 0 && (wrench || fast)) {
+  } else if (B > 0 && wrench) {
     if (h->cfg.dtype == MPCQP_DTYPE_F64) {
       const FastIn<double> in = {(const double*)x0, (const double*)r, contact, (const double*)xdes, (const double*)mu,
                                  nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const double*)u_out : nullptr, ys, shift};
-      he = wrench ? launch_wrench_n<double>(h, B, in, u_out, X_out, status, iters, res, st)
-                  : launch_fast<double>(h, B, in, u_out, X_out, status, iters, res, st);
+      he = launch_wrench_n<double>(h, B, in, u_out, X_out, status, iters, res, st);
     } else {
       const FastIn<float> in = {(const float*)x0, (const float*)r, contact, (const float*)xdes, (const float*)mu,
                                 nullptr, nullptr, nullptr, nullptr, nullptr, warm ? (const float*)u_out : nullptr, ys, shift};
-      he = wrench ? launch_wrench_n<float>(h, B, in, u_out, X_out, status, iters, res, st)
-                  : launch_fast<float>(h, B, in, u_out, X_out, status, iters, res, st);
+      he = launch_wrench_n<float>(h, B, in, u_out, X_out, status, iters, res, st);
     }
-    if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
-  } else if (B > 0) {
-    const bool f64io = h->cfg.dtype == MPCQP_DTYPE_F64;
-    if (h->cfg.N == 10)
-      he = f64io ? launch_prec<double, 10>(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, st)
-                 : launch_prec<float, 10>(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, st);
-    else
-      he = f64io ? launch_prec<double, 20>(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, st)
-                 : launch_prec<float, 20>(h, B, x0, r, contact, xdes, mu, u_out, X_out, status, iters, res, st);
     if (he != hipSuccess) return fail(h, MPCQP_EHIP, "kernel launch", he);
   }
   if (timing) {

@@ -42,6 +42,7 @@ constexpr size_t SG_WS_DOUBLES = (size_t)SG_NS * SG_WS_STAGE;
 struct SmemS {
   double x0[13];
   double mu, cy, sy, rzw0[3], wP[6], wQ[6], delta, theta, alpha, inv_m, fmin, fmax, alpha_target, alpha_ok;
+  double wQ01;   // weight coupling the rotated angular-rate components 0 and 1: Rz diag(w_wx, w_wy) Rz' (zero when the omega weight is isotropic in x, y)
   double gam[SG_NQ];                   // gradient of the cost in wrench space at u = 0
   double ww[SG_NQ], kap[SG_NQ];        // wrench of the structured gradient's point, K ww + gam
   double bq[SG_NQ];                    // S y = b: the right-hand side (wrench space)
@@ -132,7 +133,10 @@ __device__ __forceinline__ void sg_factor(SmemS& s, double* __restrict__ ws, con
   if (tid < 64) {
     const int lane = tid;
     const double d = s.delta, th = s.theta, gp = th * d * d, gq = d;   // Gam = [gp I ; gq I]
-    for (int e = lane; e < 144; e += 64) { const int i = e / 12, j = e - 12 * i; s.Pi[e] = i == j ? 2.0 * (i < 6 ? s.wP[i] : s.wQ[i - 6]) : 0.0; }
+    for (int e = lane; e < 144; e += 64) {   // Pi_N = 2W (the rotated omega weight couples components 0 and 1 unless it is isotropic)
+      const int i = e / 12, j = e - 12 * i;
+      s.Pi[e] = i == j ? 2.0 * (i < 6 ? s.wP[i] : s.wQ[i - 6]) : ((i == 6 && j == 7) || (i == 7 && j == 6) ? 2.0 * s.wQ01 : 0.0);
+    }
     wsync<1>();
 #pragma unroll 1
     for (int k = N - 1; k >= 0; --k) {
@@ -209,6 +213,7 @@ __device__ __forceinline__ void sg_factor(SmemS& s, double* __restrict__ ws, con
           else if (j < 6) v = d * Mpp + Mqp;
           else v = d * d * Mpp + d * (Mpq + Mqp) + Mqq;
           if (i == j) v += 2.0 * (i < 6 ? s.wP[i] : s.wQ[i - 6]);
+          else if ((i == 6 && j == 7) || (i == 7 && j == 6)) v += 2.0 * s.wQ01;
           m[t] = v;
         }
       }
@@ -418,10 +423,12 @@ __device__ __forceinline__ void sg_adjoint(const SmemS& s, const double* __restr
   if (tid < 6) {
     const int q = tid;
     const double d = s.delta, gp = s.theta * d * d, w2p = 2.0 * s.wP[q], w2q = 2.0 * s.wQ[q];
+    const double w2c = q < 2 ? 2.0 * s.wQ01 : 0.0;   // components 0 and 1 of the rotated angular rate share a 2 x 2 weight
+    const int qc = q < 2 ? 1 - q : q;
     double lP = 0, lQ = 0;
 #pragma unroll 4
     for (int j = N - 1; j >= 0; --j) {
-      const double mP = w2p * src[12 * (j + 1) + q], mQ = w2q * src[12 * (j + 1) + 6 + q];
+      const double mP = w2p * src[12 * (j + 1) + q], mQ = fma(w2c, src[12 * (j + 1) + 6 + qc], w2q * src[12 * (j + 1) + 6 + q]);
       const double nP = lP + mP, nQ = fma(d, lP, lQ) + mQ;
       lP = nP; lQ = nQ;
       out[6 * j + q] = (base ? base[6 * j + q] : 0.0) + gp * lP + d * lQ;
@@ -806,7 +813,7 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
     SLeg Lg;
     Lg.leg = tid < NL;
     // ---- constants and inputs (src/mpc.py:242-255)
-    if (tid < 6) { s.wP[tid] = cfg.w[tid]; s.wQ[tid] = cfg.w[6 + tid]; }
+    if (tid < 6) { s.wP[tid] = cfg.w[tid]; if (tid >= 2) s.wQ[tid] = cfg.w[6 + tid]; }   // (wQ[0], wQ[1], wQ01: below, they turn with the yaw)
     if (tid == 0) {
       s.delta = cfg.delta; s.theta = cfg.theta; s.inv_m = cfg.inv_m; s.fmin = cfg.fmin; s.fmax = cfg.fmax;
       s.alpha_target = cfg.alpha > 0.0 ? cfg.alpha : ((cfg.flags & MPCQP_FLAG_POLISH) ? cfg.alpha_floor : 0.0);
@@ -843,6 +850,9 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
       s.rzw0[0] = c * s.x0[6] - sn * s.x0[7];
       s.rzw0[1] = sn * s.x0[6] + c * s.x0[7];
       s.rzw0[2] = s.x0[8];
+      // the omega weight in the rotated coordinates Q = Rz omega:  Rz diag(w6, w7) Rz'  (src/mpc.py:128-130 weights omega per world axis)
+      const double wx = cfg.w[6], wy = cfg.w[7];
+      s.wQ[0] = c * c * wx + sn * sn * wy; s.wQ[1] = sn * sn * wx + c * c * wy; s.wQ01 = c * sn * (wx - wy);
     }
     __syncthreads();
     {   // src/mpc.py:71-78, 98-107; compute_skew column a = r x e_a (src/utils.py:43-56)

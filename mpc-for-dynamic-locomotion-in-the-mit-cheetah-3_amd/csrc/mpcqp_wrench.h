@@ -4,8 +4,7 @@
 //     H = 2 alpha I + T' K T,      T = blockdiag(T_j),  T_j (6 x 12): stage forces -> [Rz tau_j ; a_j]
 //     tau_j = sum_l Ihat^-1 (r_l x f_l)   (src/mpc.py:78,98-107),   a_j = sum_l c_l f_l / m
 //     K = (+)_{q<6} K_q,   K_q[j][j'] = 2 (wP_q c1[j][j'] + wQ_q c0[j][j'])      (N x N per wrench component)
-// with c0 = d^2 (N - max(j,j')), c1 = d^4 sum_{k>max(j,j')} (k-1-j+th)(k-1-j'+th) the same stage-pair tables the
-// closed-form tile build of mpcqp_fast.h uses, wP = w[0..5] (Theta, p), wQ = w[6..11] (omega, v).  In the Rz-rotated
+// with c0 = d^2 (N - max(j,j')), c1 = d^4 sum_{k>max(j,j')} (k-1-j+th)(k-1-j'+th) the stage-pair tables mpcqp_create builds, wP = w[0..5] (Theta, p), wQ = w[6..11] (omega, v).  In the Rz-rotated
 // angular coordinates K is block diagonal in q as long as the omega weight is isotropic in x,y (the reference's is,
 // src/mpc.py:128-130) -- and then K, K^-1 are CONSTANTS of the configuration, inverted once on the host in fp64.
 // Both linear systems of the solve are "diagonal + T'KT" (ADMM: D = 2 alpha + sigma + rho G'G; polish: the same on the
@@ -20,7 +19,7 @@
 // The polish therefore builds and sweeps its S in fp64 (v_fma_f64 issues at the unpacked fp32 rate on gfx950): the
 // solve is then exact to ~1e-9 and no iterative refinement is needed (one solve + two gradients per step).
 #pragma once
-#include "mpcqp_fast.h"   // FastIn, OrderBuf, the dispatch-order pre-pass, DPP helpers
+#include "mpcqp_common.h"   // FastIn, OrderBuf, the dispatch-order pre-pass, policy constants
 
 namespace {
 
@@ -553,7 +552,7 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
     }
     s.cm[L] = st ? s.inv_m : (TV)0;
   }
-  // free response minus target, stages k = 1..N (closed forms: mpcqp_device.h struct_grad)
+  // free response minus target, stages k = 1..N (closed forms: DESIGN.md section 2)
   TV eP = 0, eQ = 0;
   if (tid < NQ) {
     const int e = tid, j = e / 6, q = e - 6 * j, k = j + 1;
@@ -619,8 +618,8 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
   return 0;
 }
 
-// Warm start (MPCQP_FLAG_WARM_START; the reference seeds every solve with its previous solution, src/mpc.py:270-271).  Same
-// contract as fast_warm_start in mpcqp_fast.h: the guess u0 (and the engine's record y0 of the previous solve's multipliers,
+// Warm start (MPCQP_FLAG_WARM_START; the reference seeds every solve with its previous solution, src/mpc.py:270-271):
+// the guess u0 (and the engine's record y0 of the previous solve's multipliers,
 // both moved up one stage with MPCQP_FLAG_WARM_SHIFT) becomes the start of the active-set iteration and of the ADMM block.
 // s.warm: 0 no guess (cold) | 1 primal guess only (unit multipliers on the rows it holds with equality) | 2 (u0, y0) is nearly
 // a KKT point | 3 (u0, y0) is only a neighbour.
@@ -1360,7 +1359,7 @@ __device__ __forceinline__ void w_output(SmemW<TV, N>& s, const WrTabs& tabs, TI
 
 // ----------------------------------------------------------------------------------------------------- the kernel
 // Plain form: blockIdx = QP.  Listed form (ob.list != null, ob.head == null): one workgroup per QP, workgroup k takes the k-th QP
-// of the dearest-expected-first order that the pre-pass of mpcqp_fast.h files; the hardware's dispatcher places the workgroups.
+// of the dearest-expected-first order that the pre-pass (mpcqp_common.h) files; the hardware's dispatcher places the workgroups.
 // Queued form (ob.head != null): only as many workgroups as the device holds, each pulling QPs from the head of that order until
 // it is empty (no workgroup turnover: the form for batches many times the device).
 template <typename TV, typename TM, typename TP, typename TIO, int N, bool REFINE = false>

@@ -177,8 +177,8 @@ def test_one_rank_rccl_bench_rehearsal():
     assert abs(j["value"] - 4096 * 3 / (j["ms_per_step"] * 3e-3)) <= 1e-6 * j["value"]
 
 
-def test_f32_request_at_horizon20_is_served_with_mixed(oracle_solve):
-    """All-fp32 arithmetic does not hold its 2e-2 band at N = 20; the product library serves PREC_F32 there with the MIXED arithmetic."""
+def test_f32_request_is_served_with_mixed(oracle_solve):
+    """MPCQP_PREC_F32 (the round-1 kernels' arithmetic) is retired: the product library serves the request with MIXED, at every horizon."""
     b = mpcqp.synth.config5(256)
     ref = oracle_solve(b, N=20)
     out = gpu_solve(b, N=20, io="f32", precision="f32")
@@ -186,6 +186,15 @@ def test_f32_request_at_horizon20_is_served_with_mixed(oracle_solve):
     assert np.array_equal(out["u"], mix["u"]) and np.array_equal(out["status"], mix["status"])
     ok = solved(out["status"])
     assert ok.mean() >= 0.99 and rel_err(out["u"], ref["u"])[ok].max() <= 1e-4
+
+
+def test_retired_kernel_flags_are_accepted_and_ignored():
+    """MPCQP_FLAG_GENERAL_KERNEL / MPCQP_FLAG_TILE_KERNEL selected the round-1 kernels; a caller that still sets them gets the engine's bits."""
+    b = mpcqp.synth.config3(256)
+    want = gpu_solve(b, io="f32", precision="mixed")
+    for fl in (4, 32, 4 | 32):
+        got = gpu_solve(b, io="f32", precision="mixed", flags=mpcqp.FLAG_POLISH | fl)
+        assert np.array_equal(got["u"], want["u"]) and np.array_equal(got["status"], want["status"])
 
 
 def test_two_handles_on_two_streams_give_the_serial_bits():

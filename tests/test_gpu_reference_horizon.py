@@ -166,16 +166,20 @@ def test_reference_horizon_nonfinite_and_ragged_batches(golden):
     assert ok.mean() >= 0.95 and rel_err(o30["u"][ok], ref["u"][ok]).max() <= 1e-4
 
 
-def test_stage_engine_zoh_and_other_constants(oracle_solve):
+@pytest.mark.parametrize("w7,precision", [(5e3, "mixed"), (4e4, "mixed"), (4e4, "f64")])
+def test_stage_engine_zoh_and_other_constants(oracle_solve, w7, precision):
     """Nothing in the stage-wise engine is tied to Euler or to the Lite3 defaults: exact zero-order hold (theta = 1/2 in Gam) and other
-    mass / inertia / weights / force bounds / alpha at N = 30, against the oracle; and the two discretisations differ (not vacuous)."""
+    mass / inertia / weights / force bounds / alpha at N = 30, against the oracle; and the two discretisations differ (not vacuous).
+    w7 != w[6]: the weight on the horizontal angular velocity is anisotropic, i.e. a yaw-dependent coupled 2 x 2 block in the body-rate
+    coordinates the recursion works in (the dense engine does not take such weights; every horizon runs them here)."""
     b = mpcqp.synth.make_batch(48, 30, 0.02, 77, ("trot", "gallop", "amble"), (0.4, 0.8))
-    kw = dict(m=12.5, Ibody_inv=[1 / 0.4, 1 / 0.9, 1 / 1.3], w=[2e4, 1e4, 3e4, 1e5, 2e5, 3e5, 5e3, 5e3, 1e4, 1e4, 2e4, 3e4, 0.0],
+    kw = dict(m=12.5, Ibody_inv=[1 / 0.4, 1 / 0.9, 1 / 1.3], w=[2e4, 1e4, 3e4, 1e5, 2e5, 3e5, 5e3, w7, 1e4, 1e4, 2e4, 3e4, 0.0],
               alpha=3e-2, f_min=5.0, f_max=150.0)
+    assert np.abs(np.sin(b["x0"][:, 2])).max() > 0.1    # yaw away from zero: the coupling term is exercised
     outs = {}
     for disc in (mpcqp.DISC_EULER, mpcqp.DISC_ZOH):
         ref = oracle_solve(b, N=30, delta=0.02, disc=disc, **kw)
-        out = gpu_solve(b, 30, 0.02, "mixed", disc=disc, **kw)
+        out = gpu_solve(b, 30, 0.02, precision, disc=disc, **kw)
         ok = out["status"] == 1
         assert ok.mean() >= 0.95, ok.mean()
         assert rel_err(out["u"], ref["u"])[ok].max() <= 1e-4 and np.abs(out["X"] - ref["X"])[ok].max() <= 1e-4

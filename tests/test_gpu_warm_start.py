@@ -136,8 +136,8 @@ def test_gait_entry_and_general_kernel_accept_the_flag(warm_setup, oracle_solve)
         ok = solved(o["status"])
         assert ok.mean() >= 0.97 and rel_err(o["u"], ref["u"])[ok].max() <= 1e-4
     assert (o2["iters"] % 1000).mean() < 0.2 * (o1["iters"] % 1000).mean()
-    # general kernel: flag accepted, cold start, same optimum
-    gen = mpcqp.MPCBatch(N=10, io_dtype="f64", precision="mixed", flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_WARM_START | 4)
+    # stage-wise engine at the same horizon: same flag, same optimum
+    gen = mpcqp.MPCBatch(N=10, io_dtype="f64", precision="mixed", flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_WARM_START | mpcqp.FLAG_STAGE_KERNEL)
     sub = {k: b[k][:64] for k in ("x0", "r", "contact", "xdes", "mu")}
     o = run(gen, sub)
     o = run(gen, sub)

@@ -19,7 +19,7 @@ rng = np.random.default_rng(0)
 idx = rng.choice(4096, NQ, replace=False)
 
 def guess(u, y, lo, hi, mu):
-    """The polish's rule (mpcqp_fast.h, ph_polish_step) per leg-stage -> tuple of (zs, xs, ys)."""
+    """The polish's rule (mpcqp_wrench.h, w_polish_rule) per leg-stage -> tuple of (zs, xs, ys)."""
     out = np.zeros((40, 3), dtype=np.int8)
     U = u.reshape(40, 3); Y = y.reshape(40, 5)
     st = hi.reshape(40, 5)[:, 0] > 0

@@ -1,5 +1,5 @@
 """Developer study: how many of the QPs that need three or four ADMM rounds are among the H dearest-PREDICTED ones of the dispatch order
-(the friction-demand predictor of mpcqp_fast.h, restated in numpy)?  Decides whether giving the first H workgroups a SIMD of their own pays."""
+(the friction-demand predictor of mpcqp_common.h, restated in numpy)?  Decides whether giving the first H workgroups a SIMD of their own pays."""
 import os, sys
 import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

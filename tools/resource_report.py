@@ -3,7 +3,7 @@ usage: python tools/resource_report.py [extra hipcc flags]"""
 import os, re, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(REPO, "mpc-for-dynamic-locomotion-in-the-mit-cheetah-3_amd", "csrc")
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-mllvm", "-amdgpu-lower-module-lds-strategy=module",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
        "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", "mpcqp_kernels.hip"] + sys.argv[1:]
 out = subprocess.run(cmd, cwd=src, capture_output=True, text=True).stderr
 cur = None

@@ -1,4 +1,4 @@
-"""Developer check on a GPU box: wrench-space engine vs the CPU oracle and vs the round-1 tile kernel (config 3)."""
+"""Developer check on a GPU box: wrench-space engine vs the CPU oracle and vs the stage-wise engine at the same horizon (config 3)."""
 import json
 import os
 import sys
@@ -42,7 +42,7 @@ def main():
     out["wrench/mixed/f32"] = run(batch, ref, "wrench mixed f32", io_dtype="f32", precision="mixed")
     out["wrench/mixed/f64"] = run(batch, ref, "wrench mixed f64", io_dtype="f64", precision="mixed")
     out["wrench/f64/f64"] = run(batch, ref, "wrench f64 f64", io_dtype="f64", precision="f64")
-    out["tile/mixed/f32"] = run(batch, ref, "tile mixed f32", io_dtype="f32", precision="mixed", flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_TILE_KERNEL)
+    out["stage/mixed/f32"] = run(batch, ref, "stage mixed f32", io_dtype="f32", precision="mixed", flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_STAGE_KERNEL)
     for K in (30, 50, 70):
         out[f"wrench/K{K}"] = run(batch, ref, f"wrench mixed f32 K={K}", io_dtype="f32", precision="mixed", check_every=K)
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
