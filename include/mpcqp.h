@@ -245,6 +245,37 @@ int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* x, void
  */
 int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* u, const void* jac, void* tau, void* stream);
 
+/*
+ * Leg geometry of the robot: three revolute joints per leg (HipX, HipY, Knee), legs FL, FR, HL, HR.  Data, not code:
+ * mpcqp_default_leg_geometry() fills the joint origins and axes of lite3_urdf/urdf/Lite3.urdf:44-124.
+ */
+typedef struct MpcQpLegGeometry {
+  uint32_t size;        /* sizeof(MpcQpLegGeometry) */
+  uint32_t reserved;
+  double hip_x[4][3];   /* HipX joint origin in the torso frame, per leg */
+  double hip_y[4][3];   /* HipY joint origin in the HipX link frame, per leg */
+  double knee[3];       /* Knee joint origin in the thigh frame */
+  double foot[3];       /* foot (sole) in the shank frame */
+  double axis_x[3];     /* HipX joint axis */
+  double axis_y[3];     /* HipY and Knee joint axis */
+} MpcQpLegGeometry;
+
+int mpcqp_default_leg_geometry(MpcQpLegGeometry* geo);
+
+/*
+ * What the reference's caller asks its physics engine for before the torque map (src/main.py:205-210:
+ * `lite3.getLinearJacobian(sole, inCoordinatesOf=World)[:, 6:9]` etc.): the world-frame 3x3 linear Jacobian block of each
+ * foot with respect to its own leg's joints, for B robots, from the joint angles -- the `jac` operand of mpcqp_torque_map.
+ *   q     T [B,4,3]     joint angles (HipX, HipY, Knee) of FL, FR, HL, HR in rad
+ *   rot   T [B,3,3]     torso orientation (world <- torso), row-major; NULL = identity (Jacobians in the torso frame)
+ *   geo                 host pointer, NULL = the Lite3 (mpcqp_default_leg_geometry)
+ *   jac   T [B,4,3,3]   out: d foot / d q of each leg, world orientation, row-major (row = axis, column = joint)
+ *   foot  T [B,4,3]     out, may be NULL: foot position relative to the torso origin, world orientation
+ * Element-wise; asynchronous on `stream`.  The oracle library exports the symbol and computes the same on host memory.
+ */
+int mpcqp_leg_jacobians(mpcqp_handle h, int64_t B, const void* q, const void* rot, const MpcQpLegGeometry* geo, void* jac,
+                        void* foot, void* stream);
+
 /* Duration in milliseconds of the most recent solve_batch's kernel(s), measured with HIP events recorded on
  * `stream` around the launch (after mpcqp_rollout: around all of its ticks); blocks until that work has finished.
  * MPCQP_EINVAL when the handle was created with MPCQP_FLAG_NO_TIMING.  Oracle: wall time of the call. */

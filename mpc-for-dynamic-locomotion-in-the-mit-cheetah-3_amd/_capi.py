@@ -26,8 +26,14 @@ FLAG_STAGE_KERNEL = 128
 
 EXPORTED_SYMBOLS = (
     "mpcqp_version", "mpcqp_default_config", "mpcqp_create", "mpcqp_destroy", "mpcqp_solve_batch",
-    "mpcqp_solve_batch_gait", "mpcqp_solve_batch_gait_steps", "mpcqp_torque_map", "mpcqp_last_kernel_ms", "mpcqp_last_error", "mpcqp_reserve", "mpcqp_rollout",
+    "mpcqp_solve_batch_gait", "mpcqp_solve_batch_gait_steps", "mpcqp_torque_map", "mpcqp_default_leg_geometry", "mpcqp_leg_jacobians", "mpcqp_last_kernel_ms", "mpcqp_last_error", "mpcqp_reserve", "mpcqp_rollout",
 )
+
+
+class MpcQpLegGeometry(ctypes.Structure):
+    """Mirror of struct MpcQpLegGeometry (include/mpcqp.h)."""
+    _fields_ = [("size", c_uint32), ("reserved", c_uint32), ("hip_x", c_double * 3 * 4), ("hip_y", c_double * 3 * 4),
+                ("knee", c_double * 3), ("foot", c_double * 3), ("axis_x", c_double * 3), ("axis_y", c_double * 3)]
 
 
 class MpcQpConfig(ctypes.Structure):
@@ -83,6 +89,10 @@ class Library:
         L.mpcqp_solve_batch_gait_steps.restype = c_int32
         L.mpcqp_torque_map.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
         L.mpcqp_torque_map.restype = c_int32
+        L.mpcqp_default_leg_geometry.argtypes = [ctypes.POINTER(MpcQpLegGeometry)]
+        L.mpcqp_default_leg_geometry.restype = c_int32
+        L.mpcqp_leg_jacobians.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, ctypes.POINTER(MpcQpLegGeometry), c_void_p, c_void_p, c_void_p]
+        L.mpcqp_leg_jacobians.restype = c_int32
         L.mpcqp_last_kernel_ms.argtypes = [c_void_p, ctypes.POINTER(c_float)]
         L.mpcqp_last_kernel_ms.restype = c_int32
         L.mpcqp_last_error.argtypes = [c_void_p]
@@ -198,6 +208,20 @@ class Engine:
         rc = self.library.lib.mpcqp_torque_map(self._h, int(B), u, jac, tau, stream or None)
         if rc != 0:
             raise MpcQpError(f"mpcqp_torque_map failed with code {rc}: {self.last_error()}")
+
+    def leg_jacobians_ptr(self, B, q, rot, jac, foot=0, geometry=None, stream=0):
+        rc = self.library.lib.mpcqp_leg_jacobians(self._h, int(B), q, rot or None, ctypes.byref(geometry) if geometry is not None else None,
+                                                  jac, foot or None, stream or None)
+        if rc != 0:
+            raise MpcQpError(f"mpcqp_leg_jacobians failed with code {rc}: {self.last_error()}")
+
+    def leg_jacobians_host(self, q, rot=None, geometry=None):
+        """Host-memory call (the CPU checker): q [B,4,3], rot [B,3,3] or None -> (jac [B,4,3,3], foot [B,4,3]), float64."""
+        q = np.ascontiguousarray(q, dtype=np.float64); B = q.shape[0]
+        rot = None if rot is None else np.ascontiguousarray(rot, dtype=np.float64)
+        jac = np.zeros((B, 4, 3, 3)); foot = np.zeros((B, 4, 3))
+        self.leg_jacobians_ptr(B, q.ctypes.data, 0 if rot is None else rot.ctypes.data, jac.ctypes.data, foot.ctypes.data, geometry)
+        return jac, foot
 
     def last_kernel_ms(self) -> float:
         ms = c_float()

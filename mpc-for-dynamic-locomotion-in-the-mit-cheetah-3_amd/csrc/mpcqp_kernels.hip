@@ -37,6 +37,98 @@ mpcqp_torque_kernel(const TIO* __restrict__ u, const TIO* __restrict__ jac, TIO*
   for (int q = 0; q < 3; ++q) tau[i * 3 + q] = J[0 * 3 + q] * fx + J[1 * 3 + q] * fy + J[2 * 3 + q] * fz;
 }
 
+// Leg kinematics (src/main.py:205-210 asks DART for these): foot position and d foot / d q of one leg from its three joint angles,
+// by composing the joint rotations (Rodrigues' formula about the geometry's axes) along the chain torso -> HipX -> HipY -> Knee -> foot.
+// One thread per (robot, leg): 3 (+9) loads, 9 (+3) stores, three sincos; fp64 arithmetic for either buffer type (the kernel is
+// launch- and HBM-latency sized: 48 B in, 108 B out per thread).
+struct LegGeoDev { double hx[4][3], hy[4][3], kn[3], ft[3], ax[3], ay[3]; };
+
+__device__ __forceinline__ void rodrigues(const double (&a)[3], const double ang, double (&R)[9]) {
+  double s, c;
+  sincos(ang, &s, &c);
+  const double t = 1.0 - c;
+  R[0] = c + t * a[0] * a[0];        R[1] = t * a[0] * a[1] - s * a[2]; R[2] = t * a[0] * a[2] + s * a[1];
+  R[3] = t * a[1] * a[0] + s * a[2]; R[4] = c + t * a[1] * a[1];        R[5] = t * a[1] * a[2] - s * a[0];
+  R[6] = t * a[2] * a[0] - s * a[1]; R[7] = t * a[2] * a[1] + s * a[0]; R[8] = c + t * a[2] * a[2];
+}
+__device__ __forceinline__ void mat3_mul(const double (&A)[9], const double (&Bm)[9], double (&C)[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * Bm[j] + A[3 * i + 1] * Bm[3 + j] + A[3 * i + 2] * Bm[6 + j];
+}
+__device__ __forceinline__ void mat3_vec(const double (&A)[9], const double (&v)[3], double (&o)[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+__device__ __forceinline__ void cross3(const double (&a)[3], const double (&b)[3], double (&o)[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+template <typename TIO>
+__global__ void __launch_bounds__(256)
+mpcqp_leg_jacobian_kernel(const TIO* __restrict__ q, const TIO* __restrict__ rot, const LegGeoDev geo, TIO* __restrict__ jac,
+                          TIO* __restrict__ foot, const int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // i = 4 b + leg
+  if (i >= 4 * B) return;
+  const int64_t b = i / 4;
+  const int l = (int)(i % 4);
+  double R1[9], Ry[9], R2[9], R3[9];
+  rodrigues(geo.ax, (double)q[3 * i], R1);
+  rodrigues(geo.ay, (double)q[3 * i + 1], Ry);
+  mat3_mul(R1, Ry, R2);
+  rodrigues(geo.ay, (double)q[3 * i + 2], Ry);
+  mat3_mul(R2, Ry, R3);
+  double hx[3], hy[3], p2[3], p3[3], pf[3], t[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { hx[a] = geo.hx[l][a]; hy[a] = geo.hy[l][a]; }   // (leg-indexed: a scalar-indexed copy per lane)
+  mat3_vec(R1, hy, t);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) p2[a] = hx[a] + t[a];
+  mat3_vec(R2, geo.kn, t);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) p3[a] = p2[a] + t[a];
+  mat3_vec(R3, geo.ft, t);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) pf[a] = p3[a] + t[a];
+  double J[9], w[3], dlt[3], col[3];   // column j = (joint axis in the torso frame) x (foot - joint origin)
+  mat3_vec(R1, geo.ax, w);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) dlt[a] = pf[a] - hx[a];
+  cross3(w, dlt, col);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) J[3 * a] = col[a];
+  mat3_vec(R2, geo.ay, w);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) dlt[a] = pf[a] - p2[a];
+  cross3(w, dlt, col);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) J[3 * a + 1] = col[a];
+  mat3_vec(R3, geo.ay, w);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) dlt[a] = pf[a] - p3[a];
+  cross3(w, dlt, col);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) J[3 * a + 2] = col[a];
+  if (rot) {   // world <- torso
+    double Rb[9], Jw[9], pw[3];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) Rb[a] = (double)rot[9 * b + a];
+    mat3_mul(Rb, J, Jw);
+    mat3_vec(Rb, pf, pw);
+#pragma unroll
+    for (int a = 0; a < 9; ++a) J[a] = Jw[a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pf[a] = pw[a];
+  }
+#pragma unroll
+  for (int a = 0; a < 9; ++a) jac[9 * i + a] = (TIO)J[a];
+  if (foot) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) foot[3 * i + a] = (TIO)pf[a];
+  }
+}
+
 // Gait entry point (mpcqp_solve_batch_gait): what MPC.solve computes on the host every tick (src/mpc.py:178-254) from the planner
 // queries (src/footstep_planner.py:226-246), for B robots at once, into the engine's own tuple workspace:
 //   x_des[k]   = [roll0, pitch0, yaw_start + k d w, com_start + k d v, 0, 0, w, v, g]             (src/mpc.py:202-214)
@@ -736,6 +828,54 @@ int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* u, const void* jac, 
                        (float*)tau, B, h->cfg.N);
   const hipError_t he = hipGetLastError();
   if (he != hipSuccess) return fail(h, MPCQP_EHIP, "torque kernel launch", he);
+  return MPCQP_OK;
+}
+
+int mpcqp_default_leg_geometry(MpcQpLegGeometry* g) {   // lite3_urdf/urdf/Lite3.urdf:44-124 (joint origins and axes; data)
+  if (!g) return MPCQP_EINVAL;
+  memset(g, 0, sizeof(*g));
+  g->size = (uint32_t)sizeof(*g);
+  for (int l = 0; l < 4; ++l) {
+    g->hip_x[l][0] = l < 2 ? 0.1745 : -0.1745;
+    g->hip_x[l][1] = (l % 2 == 0) ? 0.062 : -0.062;
+    g->hip_y[l][1] = (l % 2 == 0) ? 0.0985 : -0.0985;
+  }
+  g->knee[2] = -0.20;
+  g->foot[2] = -0.21;
+  g->axis_x[0] = -1.0;
+  g->axis_y[1] = -1.0;
+  return MPCQP_OK;
+}
+
+int mpcqp_leg_jacobians(mpcqp_handle h, int64_t B, const void* q, const void* rot, const MpcQpLegGeometry* geo, void* jac, void* foot,
+                        void* stream) {
+  if (!h) return MPCQP_EINVAL;
+  if (B < 0 || B > 0x1fffffff) return fail(h, MPCQP_EINVAL, "mpcqp_leg_jacobians: batch size out of range");
+  if (B > 0 && (!q || !jac)) return fail(h, MPCQP_EINVAL, "mpcqp_leg_jacobians: null buffer");
+  MpcQpLegGeometry lite3;
+  if (!geo) { (void)mpcqp_default_leg_geometry(&lite3); geo = &lite3; }
+  if (geo->size != sizeof(MpcQpLegGeometry)) return fail(h, MPCQP_EINVAL, "mpcqp_leg_jacobians: geometry struct size mismatch");
+  LegGeoDev g;
+  memcpy(g.hx, geo->hip_x, sizeof(g.hx)); memcpy(g.hy, geo->hip_y, sizeof(g.hy));
+  memcpy(g.kn, geo->knee, sizeof(g.kn)); memcpy(g.ft, geo->foot, sizeof(g.ft));
+  for (int k = 0; k < 2; ++k) {   // unit axes (Rodrigues' formula assumes them)
+    const double* a = k ? geo->axis_y : geo->axis_x;
+    const double nrm = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    if (!(nrm > 0) || !std::isfinite(nrm)) return fail(h, MPCQP_EINVAL, "mpcqp_leg_jacobians: zero joint axis");
+    for (int c = 0; c < 3; ++c) (k ? g.ay : g.ax)[c] = a[c] / nrm;
+  }
+  if (B == 0) return MPCQP_OK;
+  DeviceGuard guard(h->cfg.device);
+  if (guard.err != hipSuccess) return fail(h, MPCQP_EHIP, "hipSetDevice", guard.err);
+  const dim3 grid((unsigned)((4 * B + 255) / 256));
+  if (h->cfg.dtype == MPCQP_DTYPE_F64)
+    hipLaunchKernelGGL((mpcqp_leg_jacobian_kernel<double>), grid, dim3(256), 0, (hipStream_t)stream, (const double*)q, (const double*)rot, g,
+                       (double*)jac, (double*)foot, B);
+  else
+    hipLaunchKernelGGL((mpcqp_leg_jacobian_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)q, (const float*)rot, g,
+                       (float*)jac, (float*)foot, B);
+  const hipError_t he = hipGetLastError();
+  if (he != hipSuccess) return fail(h, MPCQP_EHIP, "leg Jacobian kernel launch", he);
   return MPCQP_OK;
 }
 

@@ -160,5 +160,22 @@ class MPCBatch:
         self.engine.torque_map_ptr(B, u.data_ptr(), jac.data_ptr(), tau.data_ptr(), st.cuda_stream)
         return tau
 
+    def leg_jacobians(self, q, rot=None, geometry=None, want_foot=True, stream=None):
+        """World-frame 3x3 linear Jacobian block of each foot w.r.t. its leg's joints (what src/main.py:205-210 asks DART for), on the
+        device: q [B,4,3] joint angles (HipX, HipY, Knee per leg), rot [B,3,3] torso orientation or None -> (jac [B,4,3,3], foot [B,4,3])."""
+        torch = _torch()
+        B = int(q.shape[0])
+        if tuple(q.shape) != (B, 4, 3) or q.dtype != self.tdtype or not q.is_contiguous():
+            raise ValueError("q must be a contiguous [B,4,3] tensor of the engine's dtype")
+        if rot is not None and (tuple(rot.shape) != (B, 3, 3) or rot.dtype != self.tdtype or not rot.is_contiguous()):
+            raise ValueError("rot must be a contiguous [B,3,3] tensor of the engine's dtype")
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(st):
+            jac = torch.empty((B, 4, 3, 3), dtype=self.tdtype, device=self.device)
+            foot = torch.empty((B, 4, 3), dtype=self.tdtype, device=self.device) if want_foot else None
+        self.engine.leg_jacobians_ptr(B, q.data_ptr(), rot.data_ptr() if rot is not None else 0, jac.data_ptr(),
+                                      foot.data_ptr() if foot is not None else 0, geometry, st.cuda_stream)
+        return jac, foot
+
     def last_kernel_ms(self):
         return self.engine.last_kernel_ms()

@@ -761,6 +761,84 @@ int mpcqp_rollout(mpcqp_handle h, int64_t B, int32_t T, int32_t S, void* xv, voi
   return rc;
 }
 
+/* lite3_urdf/urdf/Lite3.urdf:44-124: joint origins and axes (data). */
+int mpcqp_default_leg_geometry(MpcQpLegGeometry* g) {
+  if (!g) return MPCQP_EINVAL;
+  memset(g, 0, sizeof(*g));
+  g->size = (uint32_t)sizeof(*g);
+  const double sx[4] = {1, 1, -1, -1}, sy[4] = {1, -1, 1, -1};
+  for (int l = 0; l < 4; l++) { g->hip_x[l][0] = 0.1745 * sx[l]; g->hip_x[l][1] = 0.062 * sy[l]; g->hip_y[l][1] = 0.0985 * sy[l]; }
+  g->knee[2] = -0.20; g->foot[2] = -0.21; g->axis_x[0] = -1.0; g->axis_y[1] = -1.0;
+  return MPCQP_OK;
+}
+
+/* Foot position of one leg in the torso frame: the chain of homogeneous transforms torso -> HipX -> HipY -> Knee -> foot, each joint a
+ * rotation exp(angle [axis]x) summed as its power series (checker: no closed form shared with the device kernel). */
+static void rot_series(const double* axis, double ang, double R[9]) {
+  const double n = sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+  const double a[3] = {axis[0] / n * ang, axis[1] / n * ang, axis[2] / n * ang};
+  const double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+  double term[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, nxt[9];
+  for (int i = 0; i < 9; i++) R[i] = term[i];
+  for (int k = 1; k < 40; k++) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) nxt[3 * i + j] = (term[3 * i] * K[j] + term[3 * i + 1] * K[3 + j] + term[3 * i + 2] * K[6 + j]) / k;
+    for (int i = 0; i < 9; i++) { term[i] = nxt[i]; R[i] += term[i]; }
+  }
+}
+static void leg_fk(const MpcQpLegGeometry* g, int l, const double q[3], double pf[3]) {
+  double R[3][9];
+  rot_series(g->axis_x, q[0], R[0]); rot_series(g->axis_y, q[1], R[1]); rot_series(g->axis_y, q[2], R[2]);
+  const double* off[3] = {g->hip_y[l], g->knee, g->foot};
+  double v[3] = {0, 0, 0};
+  for (int j = 2; j >= 0; j--) {   /* innermost link first: v <- R_j (off_j + v) */
+    double t[3] = {off[j][0] + v[0], off[j][1] + v[1], off[j][2] + v[2]};
+    for (int i = 0; i < 3; i++) v[i] = R[j][3 * i] * t[0] + R[j][3 * i + 1] * t[1] + R[j][3 * i + 2] * t[2];
+  }
+  for (int i = 0; i < 3; i++) pf[i] = g->hip_x[l][i] + v[i];
+}
+
+/* src/main.py:205-210: the world-frame linear Jacobian block of each foot w.r.t. its leg's joints.  Checker: central differences of
+ * the forward kinematics with Richardson extrapolation (error ~ h^4), then rotated by the torso orientation. */
+int mpcqp_leg_jacobians(mpcqp_handle h, int64_t B, const void* qv, const void* rotv, const MpcQpLegGeometry* geo, void* jacv, void* footv,
+                        void* stream) {
+  (void)stream;
+  if (!h || B < 0 || (B > 0 && (!qv || !jacv))) return MPCQP_EINVAL;
+  MpcQpLegGeometry lite3;
+  if (!geo) { mpcqp_default_leg_geometry(&lite3); geo = &lite3; }
+  if (geo->size != sizeof(MpcQpLegGeometry)) return MPCQP_EINVAL;
+  const double *q = (const double*)qv, *rot = (const double*)rotv;
+  double *jac = (double*)jacv, *foot = (double*)footv;
+  for (int64_t i = 0; i < 4 * B; i++) {
+    const int l = (int)(i % 4);
+    double J[9], pf[3];
+    leg_fk(geo, l, q + 3 * i, pf);
+    for (int j = 0; j < 3; j++) {
+      double d1[3], d2[3];
+      for (int pass = 0; pass < 2; pass++) {
+        const double hh = pass ? 2e-3 : 1e-3;
+        double qp[3] = {q[3 * i], q[3 * i + 1], q[3 * i + 2]}, qm[3] = {q[3 * i], q[3 * i + 1], q[3 * i + 2]}, fp[3], fm[3];
+        qp[j] += hh; qm[j] -= hh;
+        leg_fk(geo, l, qp, fp); leg_fk(geo, l, qm, fm);
+        for (int a = 0; a < 3; a++) (pass ? d2 : d1)[a] = (fp[a] - fm[a]) / (2 * hh);
+      }
+      for (int a = 0; a < 3; a++) J[3 * a + j] = (4 * d1[a] - d2[a]) / 3;
+    }
+    if (rot) {
+      const double* Rb = rot + 9 * (i / 4);
+      double Jw[9], pw[3];
+      for (int a = 0; a < 3; a++) {
+        for (int j = 0; j < 3; j++) Jw[3 * a + j] = Rb[3 * a] * J[j] + Rb[3 * a + 1] * J[3 + j] + Rb[3 * a + 2] * J[6 + j];
+        pw[a] = Rb[3 * a] * pf[0] + Rb[3 * a + 1] * pf[1] + Rb[3 * a + 2] * pf[2];
+      }
+      memcpy(J, Jw, sizeof(J)); memcpy(pf, pw, sizeof(pf));
+    }
+    memcpy(jac + 9 * i, J, sizeof(J));
+    if (foot) memcpy(foot + 3 * i, pf, sizeof(pf));
+  }
+  return MPCQP_OK;
+}
+
 /* src/main.py:212-214: tau[leg] = J[leg].T @ -forces[leg]; stage-0 forces only. */
 int mpcqp_torque_map(mpcqp_handle h, int64_t B, const void* uv, const void* jacv, void* tauv, void* stream) {
   (void)stream;
