@@ -53,8 +53,8 @@ struct SmemS {
   alignas(16) double zst[(SG_NS + 1) * 12];     // z_k, k = 0..N; structured gradient: the deviation states of its point (own layout)
   double PGs[SG_NS * 72];              // Pi+ Gam per stage (12 x 6, rows P_0..P_5, Q_0..Q_5), written by the factorisation
   double Es[SG_NS * 36];               // E_k = T D^-1 T' per stage
-  // factorisation scratch (wave 0)
-  double Pi[144], PG[72], Ps[36], Pinv[36], Zm[36], T1[36], Eh[36], Lm[72], Ek[36];
+  // factorisation (wave 0): operand areas of its four products
+  double Pi[144], PG[72], Ps[36];
   float red[SG_NW * 4];
   float kkt[4], resid[4];
   float gmax, rho, ratio;
@@ -92,135 +92,123 @@ __device__ __forceinline__ void xor_gather8(const T x, T (&g)[8]) {
   g[4] = dpp_mov<0x1B>(x7);
 }
 
-// In-place inverse of a 6 x 6 SPD matrix in LDS by six symmetric sweeps (lanes 0..35 of wave 0, lane = 6 i + j); the wave's LDS
-// operations are in order, wsync<1> is a compiler fence.  M <- M^-1.
-__device__ __forceinline__ void sg_inv6(double* __restrict__ M, const int lane) {
-  const int i = lane / 6, j = lane - 6 * i;
-  const bool on = lane < 36;
-#pragma unroll 1
-  for (int p = 0; p < 6; ++p) {
-    double piv = 1.0, mip = 0.0, mpj = 0.0, mij = 0.0;
-    if (on) { piv = M[7 * p]; mip = M[6 * i + p]; mpj = M[6 * p + j]; mij = M[lane]; }
-    wsync<1>();
-    const double r = w_rcp(piv);
-    double v;
-    if (i == p && j == p) v = r;
-    else if (i == p) v = mpj * r;
-    else if (j == p) v = -mip * r;
-    else v = mij - mip * mpj * r;
-    if (on) M[lane] = v;
-    wsync<1>();
-  }
+// v of lane (byte address / 4) of the wave, for a double (two crossbar moves; no LDS memory is touched).
+__device__ __forceinline__ double sg_bperm(const double v, const int byte_addr) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(unsigned)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int LANE>
+__device__ __forceinline__ double sg_readlane(const double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, LANE), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), LANE);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// C (6 x 6) = A (6 x 6) * B (6 x 6), all in LDS; lanes 0..35.  Ends with a fence.
-__device__ __forceinline__ void sg_mm6(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ Bm, const int lane) {
-  if (lane < 36) {
-    const int i = lane / 6, j = lane - 6 * i;
-    double a = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) a = fma(A[6 * i + k], Bm[6 * k + j], a);
-    C[lane] = a;
+// Inverse of a symmetric positive definite 6 x 6 matrix held one entry per lane on the wave's 8 x 8 grid (lane = 8 i + j; i, j < 6
+// carry the matrix): six symmetric sweeps, M <- -M^-1, the pivot row fetched through the crossbar (by symmetry it is the pivot
+// column too) and the pivot itself through a scalar register -- no LDS round trip in a sweep.  Lanes off the 6 x 6 grid carry zeros
+// that nothing reads.
+__device__ __forceinline__ double sg_inv6_reg(double m, const int i, const int j) {
+#define SG_SWEEP(P)                                                                   \
+  {                                                                                   \
+    const double rpj = sg_bperm(m, 4 * (8 * P + j)), rpi = sg_bperm(m, 4 * (8 * P + i)); \
+    const double r = w_rcp(sg_readlane<9 * P>(m));                                    \
+    const double upd = fma(-rpi * r, rpj, m);                                         \
+    m = (i == P) ? ((j == P) ? -r : rpj * r) : ((j == P) ? rpi * r : upd);            \
   }
-  wsync<1>();
+  SG_SWEEP(0) SG_SWEEP(1) SG_SWEEP(2) SG_SWEEP(3) SG_SWEEP(4) SG_SWEEP(5)
+#undef SG_SWEEP
+  return -m;
 }
 
 // Riccati factorisation for the E_k blocks in s.Es (fp64), by wave 0; the other waves wait at the closing barrier.
 // Writes per stage: Lrow / Lcol (the rows / columns of L = Pi+ Gam Ehat in the butterfly order of the two chains; fp32 -> LDS,
 // fp64 -> workspace) and PG = Pi+ Gam (LDS).
+// The N stages are a dependent sequence and each is a handful of 6 x 6 operations, so what a stage costs is its count of
+// DEPENDENT memory round trips, not its flops.  Pi (12 x 12) therefore lives in registers as its four 6 x 6 blocks, lane (i, j) of
+// the wave's 8 x 8 grid holding entry (i, j) of each: Pi Gam, Psi = Gam' Pi Gam and Phi' M Phi are then lane-local, transposes and
+// the two 6 x 6 inverses go through the crossbar (sg_inv6_reg), and only the four products (Z E, Psi^-1 (Z E), PG Ehat, L PG') read
+// operand rows from LDS -- four round trips per stage (the first form of this routine kept every matrix in LDS: ~40 round trips,
+// 10 k cycles per stage, a third of a solve at N = 60; tools/stage_stamps.py).
 template <typename TM>
 __device__ __forceinline__ void sg_factor(SmemS& s, double* __restrict__ ws, const int N, const int tid) {
   if (tid < 64) {
-    const int lane = tid;
+    const int i = tid >> 3, j = tid & 7;
+    const bool on = i < 6 && j < 6;
+    const int ii = min(i, 5), jj = min(j, 5);                 // (addresses of the lanes off the grid stay inside the arrays)
+    const int tp = 4 * (8 * j + i);                           // the transposed entry's lane
     const double d = s.delta, th = s.theta, gp = th * d * d, gq = d;   // Gam = [gp I ; gq I]
-    for (int e = lane; e < 144; e += 64) {   // Pi_N = 2W (the rotated omega weight couples components 0 and 1 unless it is isotropic)
-      const int i = e / 12, j = e - 12 * i;
-      s.Pi[e] = i == j ? 2.0 * (i < 6 ? s.wP[i] : s.wQ[i - 6]) : ((i == 6 && j == 7) || (i == 7 && j == 6) ? 2.0 * s.wQ01 : 0.0);
-    }
-    wsync<1>();
+    const double w2P = (on && i == j) ? 2.0 * s.wP[ii] : 0.0;
+    const double w2Q = !on ? 0.0 : (i == j ? 2.0 * s.wQ[ii] : (i + j == 1 ? 2.0 * s.wQ01 : 0.0));   // (the rotated omega weight couples 0 and 1)
+    double PP = w2P, PQ = 0.0, QP = 0.0, QQ = w2Q;            // Pi_N = 2W
+    // LDS operand areas of the four products (the former scratch matrices of this routine)
+    double* const A6 = s.Pi;          // 36: left operand of a 6 x 6 product
+    double* const B6 = s.Pi + 36;     // 36: right operand
+    double* const GPm = s.Pi + 72;    // 36: PG rows P
+    double* const GQm = s.Pi + 108;   // 36: PG rows Q
+    double* const LPm = s.PG;         // 36: L rows P
+    double* const LQm = s.PG + 36;    // 36: L rows Q
+    double* const EHm = s.Ps;         // 36: Ehat
+    double En = on ? s.Es[36 * (N - 1) + 6 * ii + jj] : 0.0;
 #pragma unroll 1
     for (int k = N - 1; k >= 0; --k) {
-      double* fac = ws + (size_t)k * SG_WS_STAGE;
-      if (lane < 36) s.Ek[lane] = s.Es[36 * k + lane];
-      // PG = Pi Gam (12 x 6)
-      for (int e = lane; e < 72; e += 64) { const int i = e / 6, c = e - 6 * i; s.PG[e] = gp * s.Pi[12 * i + c] + gq * s.Pi[12 * i + 6 + c]; }
+      const double E = En;
+      En = on ? s.Es[36 * max(k - 1, 0) + 6 * ii + jj] : 0.0;   // next stage's block, early
+      const double gP = on ? gp * PP + gq * PQ : 0.0, gQ = on ? gp * QP + gq * QQ : 0.0;   // PG = Pi Gam: rows P_i / Q_i, column j
+      double psi = gp * gP + gq * gQ;                                                       // Psi = Gam' PG
+      psi = 0.5 * (psi + sg_bperm(psi, tp));
+      const double pinv = sg_inv6_reg(on ? psi : 0.0, i, j);
+      const double zm = sg_inv6_reg(on ? pinv + E : 0.0, i, j);                             // Z = (Psi^-1 + E)^-1
+      if (on) { A6[6 * ii + jj] = zm; B6[6 * ii + jj] = E; GPm[6 * ii + jj] = gP; GQm[6 * ii + jj] = gQ; }
       wsync<1>();
-      // Psi = Gam' PG (6 x 6, symmetric), inverted in place
-      if (lane < 36) { const int a = lane / 6, c = lane - 6 * a; const double v = gp * s.PG[6 * a + c] + gq * s.PG[6 * (6 + a) + c]; s.Ps[lane] = v; }
-      wsync<1>();
-      if (lane < 36) { const int a = lane / 6, c = lane - 6 * a; s.Pinv[lane] = 0.5 * (s.Ps[lane] + s.Ps[6 * c + a]); }
-      wsync<1>();
-      sg_inv6(s.Pinv, lane);
-      if (lane < 36) s.Zm[lane] = s.Pinv[lane] + s.Ek[lane];
-      wsync<1>();
-      sg_inv6(s.Zm, lane);
-      sg_mm6(s.T1, s.Zm, s.Ek, lane);           // Z E
-      sg_mm6(s.Ps, s.Pinv, s.T1, lane);         // Psi^-1 Z E (Ps reused)
-      if (lane < 36) { const int a = lane / 6, c = lane - 6 * a; s.Eh[lane] = 0.5 * (s.Ps[lane] + s.Ps[6 * c + a]); }
-      wsync<1>();
-      // L = PG Ehat (12 x 6)
-      for (int e = lane; e < 72; e += 64) {
-        const int i = e / 6, c = e - 6 * i;
-        double a = 0;
+      double t1 = 0.0;                                                                      // Z E
 #pragma unroll
-        for (int q = 0; q < 6; ++q) a = fma(s.PG[6 * i + q], s.Eh[6 * q + c], a);
-        s.Lm[e] = a;
+      for (int q = 0; q < 6; ++q) t1 = fma(A6[6 * ii + q], B6[6 * q + jj], t1);
+      wsync<1>();
+      if (on) { A6[6 * ii + jj] = pinv; B6[6 * ii + jj] = t1; }
+      wsync<1>();
+      double eh = 0.0;                                                                      // Psi^-1 Z E  (= (I + E Psi)^-1 E)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) eh = fma(A6[6 * ii + q], B6[6 * q + jj], eh);
+      eh = on ? 0.5 * (eh + sg_bperm(eh, tp)) : 0.0;
+      if (on) EHm[6 * ii + jj] = eh;
+      wsync<1>();
+      double lP = 0.0, lQ = 0.0;                                                            // L = PG Ehat
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { const double e = EHm[6 * q + jj]; lP = fma(GPm[6 * ii + q], e, lP); lQ = fma(GQm[6 * ii + q], e, lQ); }
+      if (!on) { lP = 0.0; lQ = 0.0; }
+      if (on) { LPm[6 * ii + jj] = lP; LQm[6 * ii + jj] = lQ; }
+      // factors out (TM): butterfly layouts of the chains (group lane c, slot sl: partner c ^ sl; Lrow: c = row, Lcol: c = column), PG row-major
+      if constexpr (sizeof(TM) == 4) {
+        float* fr = reinterpret_cast<float*>(s.fbuf) + 128 * k, *fc = fr + SG_NS * 128;
+        fr[16 * i + (i ^ j)] = (float)lP; fr[16 * i + 8 + (i ^ j)] = (float)lQ;
+        fc[16 * j + (i ^ j)] = (float)lP; fc[16 * j + 8 + (i ^ j)] = (float)lQ;
+      } else {
+        double* fac = ws + (size_t)k * SG_WS_STAGE;
+        fac[16 * i + (i ^ j)] = lP; fac[16 * i + 8 + (i ^ j)] = lQ;
+        fac[128 + 16 * j + (i ^ j)] = lP; fac[128 + 16 * j + 8 + (i ^ j)] = lQ;
+      }
+      if (on) { s.PGs[72 * k + 6 * ii + jj] = gP; s.PGs[72 * k + 36 + 6 * ii + jj] = gQ; }
+      wsync<1>();
+      // M = Pi - L PG', symmetrised;  Pi <- 2W + Phi' M Phi = [[Mpp, d Mpp + Mpq], [d Mpp + Mqp, d^2 Mpp + d (Mpq + Mqp) + Mqq]]
+      double mPP = 0.5 * (PP + sg_bperm(PP, tp)), mQQ = 0.5 * (QQ + sg_bperm(QQ, tp));
+      double mPQ = 0.5 * (PQ + sg_bperm(QP, tp)), mQP = 0.5 * (QP + sg_bperm(PQ, tp));
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const double lPi = LPm[6 * ii + q], lQi = LQm[6 * ii + q], lPj = LPm[6 * jj + q], lQj = LQm[6 * jj + q];
+        const double gPi = GPm[6 * ii + q], gQi = GQm[6 * ii + q], gPj = GPm[6 * jj + q], gQj = GQm[6 * jj + q];
+        mPP -= 0.5 * (lPi * gPj + lPj * gPi);
+        mPQ -= 0.5 * (lPi * gQj + lQj * gPi);
+        mQP -= 0.5 * (lQi * gPj + lPj * gQi);
+        mQQ -= 0.5 * (lQi * gQj + lQj * gQi);
       }
       wsync<1>();
-      // factors out (TM): butterfly layouts for the chains (group lane c, slot sl: partner j = c ^ sl), PG row-major
-      for (int e = lane; e < 128; e += 64) {
-        const int c = e >> 4, sl = e & 7, hi = (e >> 3) & 1, j = c ^ sl;
-        const bool okc = c < 6 && j < 6;
-        const TM lr = okc ? (TM)s.Lm[6 * (6 * hi + c) + j] : (TM)0;            // Lrow: rows P_c (hi = 0) / Q_c (hi = 1), column j
-        const TM lc = okc ? (TM)s.Lm[6 * (6 * hi + j) + c] : (TM)0;            // Lcol: column c, rows P_j / Q_j
-        if constexpr (sizeof(TM) == 4) {
-          reinterpret_cast<float*>(s.fbuf)[128 * k + e] = lr;
-          reinterpret_cast<float*>(s.fbuf)[SG_NS * 128 + 128 * k + e] = lc;
-        } else {
-          fac[e] = (double)lr;
-          fac[128 + e] = (double)lc;
-        }
-      }
-      for (int e = lane; e < 72; e += 64) s.PGs[72 * k + e] = s.PG[e];
-      // Pi <- 2W + Phi' (Pi - L PG') Phi,  symmetrised.  M = Pi - L PG' first (each lane three entries, read before any write)
-      double m[3];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int e = lane + 64 * t;
-        m[t] = 0;
-        if (e < 144) {
-          const int i = e / 12, j = e - 12 * i;
-          double a = 0.5 * (s.Pi[e] + s.Pi[12 * j + i]);
-#pragma unroll
-          for (int q = 0; q < 6; ++q) a -= 0.5 * (s.Lm[6 * i + q] * s.PG[6 * j + q] + s.Lm[6 * j + q] * s.PG[6 * i + q]);
-          m[t] = a;
-        }
-      }
-      wsync<1>();
-#pragma unroll
-      for (int t = 0; t < 3; ++t) { const int e = lane + 64 * t; if (e < 144) s.Pi[e] = m[t]; }
-      wsync<1>();
-      // Phi' M Phi = [[Mpp, d Mpp + Mpq], [d Mpp + Mqp, d^2 Mpp + d (Mpq + Mqp) + Mqq]]
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int e = lane + 64 * t;
-        if (e < 144) {
-          const int i = e / 12, j = e - 12 * i, ib = i % 6, jb = j % 6;
-          const double Mpp = s.Pi[12 * ib + jb], Mpq = s.Pi[12 * ib + 6 + jb], Mqp = s.Pi[12 * (6 + ib) + jb], Mqq = s.Pi[12 * (6 + ib) + 6 + jb];
-          double v;
-          if (i < 6 && j < 6) v = Mpp;
-          else if (i < 6) v = d * Mpp + Mpq;
-          else if (j < 6) v = d * Mpp + Mqp;
-          else v = d * d * Mpp + d * (Mpq + Mqp) + Mqq;
-          if (i == j) v += 2.0 * (i < 6 ? s.wP[i] : s.wQ[i - 6]);
-          else if ((i == 6 && j == 7) || (i == 7 && j == 6)) v += 2.0 * s.wQ01;
-          m[t] = v;
-        }
-      }
-      wsync<1>();
-#pragma unroll
-      for (int t = 0; t < 3; ++t) { const int e = lane + 64 * t; if (e < 144) s.Pi[e] = m[t]; }
-      wsync<1>();
+      PP = on ? mPP + w2P : 0.0;
+      PQ = on ? fma(d, mPP, mPQ) : 0.0;
+      QP = on ? fma(d, mPP, mQP) : 0.0;
+      QQ = on ? fma(d * d, mPP, fma(d, mPQ + mQP, mQQ)) + w2Q : 0.0;
     }
   }
   __syncthreads();
@@ -617,12 +605,14 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
   int it = 0, seg_end = (adapt && MPCQP_W_ADAPT_AT < K) ? MPCQP_W_ADAPT_AT : K;
   int hard = 0;
   float ratio = 0.f;
+  STAMP_INIT
   __syncthreads();   // (everyone has read s.rho / s.iters)
   for (;;) {
     LegSys<double> Ls;
     sg_admm_sys(s, cfg, Lg, (double)rho, Ls);
     sg_build_E(s, Ls, Lg.leg, tid);
     sg_factor<TM>(s, ws, N, tid);
+    STAMP(1);
     const double sigma = cfg.sigma, relax = cfg.relax, om = 1.0 - relax, BIG = 1e30, r = (double)rho, mu = s.mu;
     double u[3], z[5], yh[5];
 #pragma unroll
@@ -665,6 +655,7 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
           z[k] = zn;
         }
       }
+      STAMP(2);
       if (it >= K) break;
       {
         double y5[5];
@@ -672,6 +663,7 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
         for (int k = 0; k < 5; ++k) y5[k] = r * yh[k];
         ratio = sg_ratio(s, Lg, u, z, y5, N, tid);
       }
+      STAMP(3);
       if (ratio > cfg.adapt_thr) { rebuild = true; break; }   // uniform
       seg_end = K;
     }
@@ -696,6 +688,7 @@ __device__ __forceinline__ int sg_polish_round(SmemS& s, const DevCfg& cfg, SLeg
                                                const int N, const int tid) {
   int ok = 0, ps = 0, nstall = 0;
   float vprev = INFINITY, vprev2 = INFINITY;
+  STAMP_INIT
   for (;;) {
     const int code = sg_polish_rule(s, Lg);
     if (Lg.leg) s.aset[tid] = (uint8_t)code;
@@ -714,8 +707,10 @@ __device__ __forceinline__ int sg_polish_round(SmemS& s, const DevCfg& cfg, SLeg
     const ActSet as(code, Lg.stance);
     LegSys<double> Ls;
     sg_polish_sys(s, Lg, as, Ls);
+    STAMP(7);
     sg_build_E(s, Ls, Lg.leg, tid);
     sg_factor<double>(s, ws, N, tid);
+    STAMP(4);
     const int zs = as.zs, xs = as.xs, ys = as.ys;
     const bool ez = as.ez, ex = as.ex, ey = as.ey;
     const double muv = s.mu, txs = (double)xs * muv, tys = (double)ys * muv;
@@ -730,6 +725,7 @@ __device__ __forceinline__ int sg_polish_round(SmemS& s, const DevCfg& cfg, SLeg
     for (int rf = 0;; ++rf) {
       uc[2] = v3[2]; uc[0] = ex ? v3[0] : txs * v3[2]; uc[1] = ey ? v3[1] : tys * v3[2];
       sg_grad(s, Lg, uc, gr3, N, tid);
+      STAMP(5);
       const double rg[3] = {ex ? gr3[0] : 0.0, ey ? gr3[1] : 0.0, ez ? gr3[2] + txs * gr3[0] + tys * gr3[1] : 0.0};
       float q[2] = {Lg.leg ? fmaxf(fmaxf(fabsf((float)rg[0]), fabsf((float)rg[1])), fabsf((float)rg[2])) : 0.f,
                     Lg.leg ? fmaxf(fmaxf(fabsf((float)uc[0]), fabsf((float)uc[1])), fabsf((float)uc[2])) : 0.f};
@@ -747,6 +743,7 @@ __device__ __forceinline__ int sg_polish_round(SmemS& s, const DevCfg& cfg, SLeg
       double dx[3];
       sg_leg_solve<double>(s, ws, Ls, rhs, dx, Lg.leg, N, tid);
       v3[0] += ex ? dx[0] : 0.0; v3[1] += ey ? dx[1] : 0.0; v3[2] += ez ? dx[2] : 0.0;
+      STAMP(6);
     }
     // duals from stationarity, primal feasibility + dual sign (thresholds: the fp64-buffer set of mpcqp_wrench.h)
     const double fminv = s.fmin, fmaxv = s.fmax;
@@ -812,6 +809,7 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
   for (int b = blockIdx.x; b < Btot; b += gridDim.x) {
     SLeg Lg;
     Lg.leg = tid < NL;
+    STAMP_INIT
     // ---- constants and inputs (src/mpc.py:242-255)
     if (tid < 6) { s.wP[tid] = cfg.w[tid]; if (tid >= 2) s.wQ[tid] = cfg.w[6 + tid]; }   // (wQ[0], wQ[1], wQ01: below, they turn with the yaw)
     if (tid == 0) {
@@ -912,6 +910,7 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
 #pragma unroll
     for (int i = 0; i < 5; ++i) { Lg.za[i] = 0; Lg.ya[i] = 0; Lg.py[i] = 0; }
     __syncthreads();
+    STAMP(0);
     // ---- rounds: ADMM block, polish steps; on failure OSQP's rho adaptation and another round (mpcqp_wrench.h, same policy)
     const int max_iter = cfg.max_iter, polish_max = cfg.polish_max;
     const bool admm_only = !(cfg.flags & MPCQP_FLAG_POLISH);
@@ -978,6 +977,7 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
 #pragma unroll
       for (int a = 0; a < 3; ++a) Lg.uv[a] = keep_u[a];
     }
+    STAMP(9);   // (all rounds: the phases inside stamp themselves, 1..7)
     // ---- outputs (src/mpc.py:265-268)
     double f[3];
 #pragma unroll
@@ -1018,6 +1018,7 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
       if (resg) { resg[2 * b] = s.kkt[1]; resg[2 * b + 1] = fmaxf(s.kkt[2], s.kkt[0]); }
     }
     __syncthreads();
+    STAMP(8);
   }
 }
 
