@@ -33,6 +33,7 @@ namespace {
 constexpr int SG_NS = 64;                 // stages a workgroup can hold
 constexpr int SG_NT = 256, SG_NW = 4;     // one lane per leg-stage
 constexpr int SG_NQ = 6 * SG_NS;
+constexpr int SG_TL_MIN = 24;             // horizons from which the two recursions of a solve run two-level (eight chunks in parallel)
 constexpr double SG_ALPHA_FLOOR = 2e-5;   // where this engine's continuation of an alpha = 0 request ends (mpcqp_kernels.hip)
 // Workspace of one resident workgroup, in doubles: the fp64 chains' factor matrices, per stage  Lrow (128) | Lcol (128)  (the fp32
 // chains keep theirs in LDS for the whole ADMM block).
@@ -55,6 +56,11 @@ struct SmemS {
   double Es[SG_NS * 36];               // E_k = T D^-1 T' per stage
   // factorisation (wave 0): operand areas of its four products
   double Pi[144], PG[72], Ps[36];
+  // two-level chains (horizons >= SG_TL_MIN): transition matrices of the inner chunks, T_g = A_lo .. A_(hi-1) with A_k = Phi' (I - L_k Gam'),
+  // 12 x 12 row-major over (P_0..P_5, Q_0..Q_5), in the chains' element type (fp32: T and T' per chunk, fp64: T only), and the chunks'
+  // local results
+  alignas(16) double Tc[6 * 144];
+  alignas(16) double cmb[8 * 12];
   float red[SG_NW * 4];
   float kkt[4], resid[4];
   float gmax, rho, ratio;
@@ -133,7 +139,7 @@ __device__ __forceinline__ double sg_inv6_reg(double m, const int i, const int j
 // operand rows from LDS -- four round trips per stage (the first form of this routine kept every matrix in LDS: ~40 round trips,
 // 10 k cycles per stage, a third of a solve at N = 60; tools/stage_stamps.py).
 template <typename TM>
-__device__ __forceinline__ void sg_factor(SmemS& s, double* __restrict__ ws, const int N, const int tid) {
+__device__ __forceinline__ void sg_factor(SmemS& s, double* __restrict__ ws, const int N, const int tid, const bool chunks = false) {
   if (tid < 64) {
     const int i = tid >> 3, j = tid & 7;
     const bool on = i < 6 && j < 6;
@@ -212,6 +218,49 @@ __device__ __forceinline__ void sg_factor(SmemS& s, double* __restrict__ ws, con
     }
   }
   __syncthreads();
+  if (chunks && N >= SG_TL_MIN) {   // (uniform) transition matrices of the inner chunks: lane = (chunk, column), the column pushed through its stages
+    const int CH = (N + 7) >> 3, G = (N + CH - 1) / CH;
+    if (tid < 72) {
+      const int m = tid / 12, col = tid - 12 * m, g = m + 1;
+      if (g <= G - 2) {
+        // in the chains' own arithmetic and from the factors in the rounding the chains use (Lrow layout: row c, slot c ^ column)
+        const TM d = (TM)s.delta, gp = (TM)(s.theta * s.delta * s.delta), gq = d;
+        TM v[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) v[r] = r == col ? (TM)1 : (TM)0;
+#pragma unroll 1
+        for (int k = min(N, (g + 1) * CH) - 1; k >= g * CH; --k) {
+          TM w[6];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) w[q] = gp * v[q] + gq * v[6 + q];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            TM lP[8], lQ[8];
+            if constexpr (sizeof(TM) == 4) {
+              const float* fr = reinterpret_cast<const float*>(s.fbuf) + 128 * k + 16 * i;
+              ld8<float>(fr, lP); ld8<float>(fr + 8, lQ);
+            } else {
+              const double* fr = ws + (size_t)k * SG_WS_STAGE + 16 * i;
+              ld8<double>(fr, lP); ld8<double>(fr + 8, lQ);
+            }
+            TM aP = v[i], aQ = v[6 + i];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { aP = fma(-lP[i ^ q], w[q], aP); aQ = fma(-lQ[i ^ q], w[q], aQ); }
+            v[i] = aP; v[6 + i] = fma(d, aP, aQ);
+          }
+        }
+        // fp32: T and T' (each chain reads contiguous rows); fp64: T only (room for one)
+        TM* T = reinterpret_cast<TM*>(s.Tc) + (sizeof(TM) == 4 ? 288 : 144) * m;
+#pragma unroll
+        for (int r = 0; r < 12; ++r) T[12 * r + col] = v[r];
+        if constexpr (sizeof(TM) == 4) {
+#pragma unroll
+          for (int r = 0; r < 12; ++r) T[144 + 12 * col + r] = v[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // E_k = sum_legs A diag(dinv) A' (fp64) -> LDS.  Leg lanes (a quad = a stage).  Ends with a barrier.
@@ -240,6 +289,41 @@ __device__ __forceinline__ void sg_build_E(SmemS& s, const LegSys<double>& L, co
   __syncthreads();
 }
 
+// One combine step of the two-level chains: out = R' x with lane c of each group holding x[P_c], x[Q_c] and rows P_c, Q_c of R
+// (12 entries each over P_0..P_5, Q_0..Q_5): twelve partial outputs per lane, reduce-scattered over the group -- lane c gets out[P_c],
+// out[Q_c].  R = T for the forward recursion (out = T' z) and T' for the backward one (out = T pi).  Lanes 6, 7 of a group hold zeros.
+template <typename TM>
+__device__ __forceinline__ void sg_combine(const TM (&R)[24], const TM xp, const TM xq, const int c, TM& op, TM& oq) {
+  TM vP[8], vQ[8];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) { vP[r] = fma(R[12 + r], xq, R[r] * xp); vQ[r] = fma(R[18 + r], xq, R[6 + r] * xp); }
+  vP[6] = vP[7] = vQ[6] = vQ[7] = (TM)0;
+  op = rs8<TM>(vP, c);
+  oq = rs8<TM>(vQ, c);
+}
+// rows P_c, Q_c of a 12 x 12 row-major matrix (contiguous)
+__device__ __forceinline__ void sg_ld_rows(const float* __restrict__ M, const int c, float (&R)[24]) {
+  const float4* a = reinterpret_cast<const float4*>(M + 12 * c);
+  const float4* b = reinterpret_cast<const float4*>(M + 72 + 12 * c);
+#pragma unroll
+  for (int h = 0; h < 3; ++h) {
+    const float4 u = a[h], w = b[h];
+    R[4 * h] = u.x; R[4 * h + 1] = u.y; R[4 * h + 2] = u.z; R[4 * h + 3] = u.w;
+    R[12 + 4 * h] = w.x; R[12 + 4 * h + 1] = w.y; R[12 + 4 * h + 2] = w.z; R[12 + 4 * h + 3] = w.w;
+  }
+}
+__device__ __forceinline__ void sg_ld_rows(const double* __restrict__ M, const int c, double (&R)[24]) {
+  const double2* a = reinterpret_cast<const double2*>(M + 12 * c);
+  const double2* b = reinterpret_cast<const double2*>(M + 72 + 12 * c);
+#pragma unroll
+  for (int h = 0; h < 6; ++h) { const double2 u = a[h], w = b[h]; R[2 * h] = u.x; R[2 * h + 1] = u.y; R[12 + 2 * h] = w.x; R[12 + 2 * h + 1] = w.y; }
+}
+// columns P_c, Q_c (the rows of the transpose; fp64 keeps one copy of each matrix)
+__device__ __forceinline__ void sg_ld_cols(const double* __restrict__ M, const int c, double (&R)[24]) {
+#pragma unroll
+  for (int r = 0; r < 12; ++r) { R[r] = M[12 * r + c]; R[12 + r] = M[12 * r + 6 + c]; }
+}
+
 // x = M^-1 rhs,  M = D + A-stack' K A-stack:  x = dinv (rhs - A' y),  S y = A-stack dinv rhs  by the two recursions.  All lanes call.
 //   leg lanes   a = dinv rhs,  b_k = sum_legs A a (quad sum) -> bq;  the quad's four lanes share the 12 entries of Pi+ Gam b_k -> s0
 //   chain       backward recursion (wave 0): pi_k -> pist
@@ -249,8 +333,10 @@ __device__ __forceinline__ void sg_build_E(SmemS& s, const LegSys<double>& L, co
 // Four barriers.  The chain lanes read their pair of the NEXT step and its factor rows one step ahead; nothing in a step waits for LDS.
 template <typename TM>
 __device__ __forceinline__ void sg_leg_solve(SmemS& s, const double* __restrict__ ws, const LegSys<double>& L, const double (&rhs)[3], double (&x)[3],
-                                             const bool leg, const int N, const int tid) {
+                                             const bool leg, const int N, const int tid, const bool chunks = false) {
   using T2 = std::conditional_t<sizeof(TM) == 4, float2, double2>;
+  const bool two_level = chunks && N >= SG_TL_MIN;   // (uniform; the factorisation was asked for the chunks' transition matrices)
+  const int CH = (N + 7) >> 3, G = (N + CH - 1) / CH;   // two-level: chunk g = stages [g CH, min(N, (g + 1) CH)), one per lane group of wave 0
   const double d = s.delta, th = s.theta, gp = th * d * d, gq = d;
   const int kq = min(tid, 4 * N - 1) >> 2, lq = tid & 3;
   // The recursion's vectors in the chains' element type (fp32 chains: the first half of the same bytes)
@@ -288,7 +374,86 @@ __device__ __forceinline__ void sg_leg_solve(SmemS& s, const double* __restrict_
   __syncthreads();
   const TM* const frow = reinterpret_cast<const TM*>(s.fbuf);
   const TM* const fcol = reinterpret_cast<const TM*>(s.fbuf) + (sizeof(TM) == 4 ? SG_NS * 128 : 0);
-  if (tid < 64) {   // backward chain: group 0 of wave 0 (the other groups of the wave run along on the same data)
+  if (tid < 64 && two_level) {
+    // Backward recursion, two-level: (1) every lane group runs its chunk from a zero carry, (2) the chunk results are combined serially
+    // through the transition matrices (pi_lo = rho + T pi_hi: G - 2 dense 12 x 12 steps, every group computing the same sequence and
+    // keeping the carry that enters ITS chunk), (3) every group runs its chunk again from that carry and stores.  2 CH + G - 2 dependent
+    // steps instead of N.
+    const int c = tid & 7, grp = tid >> 3;
+    const bool on6 = c < 6;
+    const TM tgp = (TM)gp, tgq = (TM)gq, td = (TM)d;
+    const int lo = grp * CH, hi = min(N, lo + CH), kmin = max(lo, 1);
+    TM pp = 0, pq = 0;
+    auto run = [&](const bool store) {
+      TM LA[16], LB[16];
+      int k = hi - 1;
+      {
+        const TM* f = frow + 128 * max(k, 0) + 16 * c;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) LA[t] = f[t];
+      }
+      T2 sA = *reinterpret_cast<const T2*>(s0 + 12 * max(k, 0) + 2 * c), sB;
+      auto step = [&](const TM (&Lr)[16], const T2& sn, TM (&Ln)[16], T2& sn2) {
+        {
+          const TM* f = frow + 128 * max(k - 1, 0) + 16 * c;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) Ln[t] = f[t];
+        }
+        sn2 = *reinterpret_cast<const T2*>(s0 + 12 * max(k - 1, 0) + 2 * c);
+        const bool valid = k >= kmin;   // (k < hi by construction; an empty chunk has hi <= lo)
+        TM sp = (on6 ? sn.x : (TM)0) + pp, sq = (on6 ? sn.y : (TM)0) + pq;
+        const TM cc = tgp * sp + tgq * sq;
+        TM g[8];
+        xor_gather8(cc, g);
+        TM a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { a0 = fma(Lr[t], g[t], a0); a1 = fma(Lr[4 + t], g[4 + t], a1); b0 = fma(Lr[8 + t], g[t], b0); b1 = fma(Lr[12 + t], g[4 + t], b1); }
+        sp -= a0 + a1; sq -= b0 + b1;
+        pp = valid ? sp : pp; pq = valid ? fma(td, sp, sq) : pq;
+        if (store && valid && on6) { T2 w; w.x = pp; w.y = pq; *reinterpret_cast<T2*>(pist + 12 * k + 2 * c) = w; }
+        --k;
+      };
+      int t = 0;
+#pragma unroll 1
+      for (; t + 1 < CH; t += 2) { step(LA, sA, LB, sB); step(LB, sB, LA, sA); }
+      if (t < CH) step(LA, sA, LB, sB);
+    };
+    run(false);
+    TM* const cmb = reinterpret_cast<TM*>(s.cmb);
+    const TM* const Tc = reinterpret_cast<const TM*>(s.Tc);
+    if (on6) { T2 w; w.x = pp; w.y = pq; *reinterpret_cast<T2*>(cmb + 12 * grp + 2 * c) = w; }
+    wsync<1>();
+    // pi entering chunk g (from above): x_(G-1) = pi_N = 0,  x_(g-1) = rho_g + T_g x_g
+    TM xp = 0, xq = 0, myp = 0, myq = 0;
+    {   // outer-product form on rows of T' (fp32: stored; fp64: the columns of T), operands of the next step fetched during this one
+      const int cr = min(c, 5);
+      TM RA[24], RB[24];
+      T2 rA, rB;
+      auto ldT = [&](const int g, TM (&R)[24]) {   // T' of chunk g
+        if constexpr (sizeof(TM) == 4) sg_ld_rows(Tc + 288 * (g - 1) + 144, cr, R);
+        else sg_ld_cols(Tc + 144 * (g - 1), cr, R);
+      };
+      auto cstep = [&](const int g, const TM (&R)[24], const T2& rho, TM (&Rn)[24], T2& rhon) {
+        if (g >= 2) ldT(g - 1, Rn);
+        rhon = *reinterpret_cast<const T2*>(cmb + 12 * max(g - 1, 0) + 2 * cr);
+        myp = grp == g ? xp : myp; myq = grp == g ? xq : myq;
+        TM ap, aq;
+        sg_combine<TM>(R, xp, xq, c, ap, aq);
+        xp = on6 ? rho.x + ap : (TM)0; xq = on6 ? rho.y + aq : (TM)0;
+      };
+      ldT(G - 2, RB);   // for the second step (G >= 7 at these horizons)
+      rA = *reinterpret_cast<const T2*>(cmb + 12 * (G - 1) + 2 * cr);
+      rB = *reinterpret_cast<const T2*>(cmb + 12 * (G - 2) + 2 * cr);
+      // g = G - 1: the carry from above is zero, no product
+      xp = on6 ? rA.x : (TM)0; xq = on6 ? rA.y : (TM)0;
+      int g = G - 2;
+#pragma unroll 1
+      for (; g >= 2; g -= 2) { cstep(g, RB, rB, RA, rA); cstep(g - 1, RA, rA, RB, rB); }
+      if (g == 1) cstep(1, RB, rB, RA, rA);
+    }
+    pp = grp == 0 ? xp : myp; pq = grp == 0 ? xq : myq;   // (group G - 1 kept its zero)
+    run(true);
+  } else if (tid < 64) {   // backward chain: group 0 of wave 0 (the other groups of the wave run along on the same data)
     const int c = tid & 7;
     const bool on6 = c < 6;
     const TM tgp = (TM)gp, tgq = (TM)gq, td = (TM)d;
@@ -344,7 +509,80 @@ __device__ __forceinline__ void sg_leg_solve(SmemS& s, const double* __restrict_
     s0[12 * k + 2 * c] = (TM)acc;
   }
   __syncthreads();
-  if (tid < 64) {   // forward chain
+  if (tid < 64 && two_level) {   // forward recursion, two-level (as above; the chunks' transition matrices are the transposes T')
+    const int c = tid & 7, grp = tid >> 3;
+    const bool on6 = c < 6;
+    const TM tgp = (TM)gp, tgq = (TM)gq, td = (TM)d;
+    const int lo = grp * CH, hi = min(N, lo + CH);
+    TM zp = 0, zq = 0;
+    auto run = [&](const bool store) {
+      TM LA[16], LB[16];
+      int k = lo;
+      {
+        const TM* f = fcol + 128 * min(k, N - 1) + 16 * c;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) LA[t] = f[t];
+      }
+      TM dA = s0[12 * min(k, N - 1) + 2 * c], dB;
+      auto step = [&](const TM (&Lc)[16], const TM dn, TM (&Ln)[16], TM& dn2) {
+        {
+          const TM* f = fcol + 128 * min(k + 1, N - 1) + 16 * c;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) Ln[t] = f[t];
+        }
+        dn2 = s0[12 * min(k + 1, N - 1) + 2 * c];
+        const bool valid = k < hi;
+        const TM dk = on6 ? dn : (TM)0;
+        const TM tp = zp + td * zq + tgp * dk, tq = zq + tgq * dk;
+        TM g0[8], g1[8];
+        xor_gather8(tp, g0);
+        xor_gather8(tq, g1);
+        TM a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { a0 = fma(Lc[t], g0[t], a0); a1 = fma(Lc[4 + t], g0[4 + t], a1); b0 = fma(Lc[8 + t], g1[t], b0); b1 = fma(Lc[12 + t], g1[4 + t], b1); }
+        const TM o = (a0 + a1) + (b0 + b1);
+        zp = valid ? tp - tgp * o : zp; zq = valid ? tq - tgq * o : zq;
+        if (store && valid && on6) { T2 w; w.x = zp; w.y = zq; *reinterpret_cast<T2*>(zst + 12 * (k + 1) + 2 * c) = w; }
+        ++k;
+      };
+      int t = 0;
+#pragma unroll 1
+      for (; t + 1 < CH; t += 2) { step(LA, dA, LB, dB); step(LB, dB, LA, dA); }
+      if (t < CH) step(LA, dA, LB, dB);
+    };
+    run(false);
+    TM* const cmb = reinterpret_cast<TM*>(s.cmb);
+    const TM* const Tc = reinterpret_cast<const TM*>(s.Tc);
+    if (on6) { T2 w; w.x = zp; w.y = zq; *reinterpret_cast<T2*>(cmb + 12 * grp + 2 * c) = w; }
+    wsync<1>();
+    // z entering chunk g (from below): x_0 = z_0 = 0,  x_(g+1) = zeta_g + T_g' x_g
+    TM xp = 0, xq = 0, myp = 0, myq = 0;
+    {
+      const int cr = min(c, 5);
+      TM RA[24], RB[24];
+      T2 rA, rB;
+      constexpr int TS = sizeof(TM) == 4 ? 288 : 144;
+      auto cstep = [&](const int g, const TM (&R)[24], const T2& zeta, TM (&Rn)[24], T2& zetan) {
+        if (g + 1 <= G - 2) sg_ld_rows(Tc + TS * g, cr, Rn);   // T of chunk g + 1, for the next step
+        zetan = *reinterpret_cast<const T2*>(cmb + 12 * min(g + 1, G - 1) + 2 * cr);
+        myp = grp == g ? xp : myp; myq = grp == g ? xq : myq;
+        TM ap, aq;
+        sg_combine<TM>(R, xp, xq, c, ap, aq);
+        xp = on6 ? zeta.x + ap : (TM)0; xq = on6 ? zeta.y + aq : (TM)0;
+      };
+      sg_ld_rows(Tc, cr, RB);   // chunk 1, for the second step
+      rA = *reinterpret_cast<const T2*>(cmb + 2 * cr);
+      rB = *reinterpret_cast<const T2*>(cmb + 12 + 2 * cr);
+      // g = 0: z_0 = 0, no product (group 0 keeps its zero)
+      xp = on6 ? rA.x : (TM)0; xq = on6 ? rA.y : (TM)0;
+      int g = 1;
+#pragma unroll 1
+      for (; g + 1 <= G - 2; g += 2) { cstep(g, RB, rB, RA, rA); cstep(g + 1, RA, rA, RB, rB); }
+      if (g <= G - 2) cstep(g, RB, rB, RA, rA);
+    }
+    zp = grp == G - 1 ? xp : myp; zq = grp == G - 1 ? xq : myq;
+    run(true);
+  } else if (tid < 64) {   // forward chain
     const int c = tid & 7;
     const bool on6 = c < 6;
     const TM tgp = (TM)gp, tgq = (TM)gq, td = (TM)d;
@@ -611,7 +849,7 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
     LegSys<double> Ls;
     sg_admm_sys(s, cfg, Lg, (double)rho, Ls);
     sg_build_E(s, Ls, Lg.leg, tid);
-    sg_factor<TM>(s, ws, N, tid);
+    sg_factor<TM>(s, ws, N, tid, true);
     STAMP(1);
     const double sigma = cfg.sigma, relax = cfg.relax, om = 1.0 - relax, BIG = 1e30, r = (double)rho, mu = s.mu;
     double u[3], z[5], yh[5];
@@ -629,7 +867,7 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
         const double w0 = v[1] + v[2], w1 = v[3] + v[4], w2 = fma(mu, (v[2] - v[1]) + (v[4] - v[3]), v[0]);
         const double rhs[3] = {fma(r, w0, fma(sigma, u[0], -Lg.g[0])), fma(r, w1, fma(sigma, u[1], -Lg.g[1])), fma(r, w2, fma(sigma, u[2], -Lg.g[2]))};
         double ut[3];
-        sg_leg_solve<TM>(s, ws, Ls, rhs, ut, Lg.leg, N, tid);
+        sg_leg_solve<TM>(s, ws, Ls, rhs, ut, Lg.leg, N, tid, true);
         if constexpr (sizeof(TM) == 8) {
           if (cfg.refine_admm) {   // tight-tolerance ADMM-only runs: one refinement step on M u~ = rhs (mpcqp_wrench.h)
             double hv[3], rr[3], du[3];
@@ -637,7 +875,7 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
             const double dg[3] = {2.0, 2.0, 1.0 + 4.0 * mu * mu};
 #pragma unroll
             for (int a = 0; a < 3; ++a) rr[a] = rhs[a] - ((hv[a] - Lg.g[a]) + (sigma + r * dg[a]) * ut[a]);
-            sg_leg_solve<TM>(s, ws, Ls, rr, du, Lg.leg, N, tid);
+            sg_leg_solve<TM>(s, ws, Ls, rr, du, Lg.leg, N, tid, true);
 #pragma unroll
             for (int a = 0; a < 3; ++a) ut[a] += du[a];
           }

@@ -8,7 +8,7 @@ from test_gpu_reference_horizon import logged_run_inputs, gpu_solve
 g = {k: np.load(os.path.join(REPO, "tests", "golden", k + ".npz")) for k in ("ref_log", "planner_golden", "qp_inputs", "qp_optima")}
 logged = logged_run_inputs(g, 60, np.arange(1000))
 synth = mpcqp.synth.make_batch(1024, 60, 0.01, 11, ("trot", "pronk", "amble", "gallop"), (0.3, 0.5, 0.7, 1.0))
-for ce, mi, pm in ((150, 2400, 8), (120, 2400, 8), (100, 2400, 8), (80, 2400, 8), (100, 2400, 12), (150, 2400, 4)):
+for ce, mi, pm in ((200, 2400, 8), (150, 2400, 8), (120, 2400, 8), (100, 2400, 8), (80, 2400, 8), (60, 2400, 8), (150, 2400, 4)):
     line = f"check_every {ce} max_iter {mi} polish_max {pm}:"
     for name, b in (("logged", logged), ("synthetic", synth)):
         o = gpu_solve(b, 60, 0.01, "mixed", alpha=1e-2, check_every=ce, max_iter=mi, polish_max=pm)
