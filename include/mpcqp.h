@@ -132,7 +132,9 @@ typedef struct MpcQpConfig {
   int32_t polish_last_patience; /* the polish patience of a round that nothing follows (iteration cap reached); 0: default (unlimited: the
                                    round uses its whole budget at N = 20, 4 at N = 10), n > 0: gives up after n steps that fail to halve the KKT violation,
                                    -1: unlimited */
-  int32_t reserved0;
+  int32_t accel;        /* Anderson acceleration of the ADMM blocks (with MPCQP_FLAG_POLISH only; an ADMM-only run is OSQP's algorithm 1
+                           unchanged): an extrapolation of the ADMM iterate every `accel` iterations from the last three; 0: default (5),
+                           -1: off.  Changes the path to the optimum (fewer iterations on slowly converging QPs), not the optimum */
 } MpcQpConfig;
 
 typedef struct mpcqp_engine* mpcqp_handle;

@@ -46,7 +46,7 @@ class MpcQpConfig(ctypes.Structure):
         ("relax", c_double), ("max_iter", c_int32), ("check_every", c_int32),
         ("eps_abs", c_double), ("eps_rel", c_double), ("polish_max", c_int32), ("device", c_int32),
         ("first_block", c_int32), ("incr_legs", c_int32), ("listed_max", c_int32), ("adapt_thr", c_float), ("alpha_floor", c_double),
-        ("polish_patience", c_int32), ("polish_cheap_steps", c_int32), ("polish_cheap_legs", c_int32), ("hard_block_x10", c_int32), ("polish_last_patience", c_int32), ("reserved0", c_int32),
+        ("polish_patience", c_int32), ("polish_cheap_steps", c_int32), ("polish_cheap_legs", c_int32), ("hard_block_x10", c_int32), ("polish_last_patience", c_int32), ("accel", c_int32),
     ]
 
     def as_dict(self):
@@ -113,8 +113,10 @@ class Library:
         if n != 10 and "check_every" not in overrides:   # scale the library's own N = 10 defaults
             # (stage-wise engine, any other horizon: an iteration costs two recursions of N steps there and a polish attempt one
             #  factorisation, so shorter blocks pay -- 2 N: 120 at the reference's N = 60, tools/stage_sweep.py: 79.9 k QP/s on the
-            #  logged ticks against 29.3 k at 10 N, 38.2 k against 20.3 k on a synthetic mixed batch, 100 % solved at both)
-            cfg.check_every = max(50, 2 * n) if stage else max(1, cfg.check_every * n // 10)
+            #  logged ticks against 29.3 k at 10 N, 38.2 k against 20.3 k on a synthetic mixed batch, 100 % solved at both; with the
+            #  Anderson-accelerated first block 5 N / 3 -- 100 at N = 60 -- tools/stage_accel.py, profiles/r03_stage_accel.txt:
+            #  logged ticks 133.6 -> 143.5 k QP/s MIXED, 89.8 -> 133.4 k F64)
+            cfg.check_every = max(50, (5 * n) // 3) if stage else max(1, cfg.check_every * n // 10)
             if "max_iter" not in overrides:
                 cfg.max_iter = max(400 if stage else 1, cfg.max_iter * n // 10)
         # ... and so is the polish budget per round: twice the leg-stages, twice the steps (N = 20, eight batches of 4096: 14 -> 3

@@ -19,10 +19,12 @@ __device__ double g_wdbg[2048];   // diagnostic builds: wrench-space engine, set
 #endif
 // Diagnostic build only (-DMPCQP_STAMPS -> libmpcqp_stamps.so): per-phase shader-cycle sums over all workgroups.
 // Never compiled into libmpcqp.so; the values leave through their own buffer and feed no output.
-#ifdef MPCQP_STAMPS
-__device__ unsigned long long g_stamps[32];
+#if defined(MPCQP_STAMPS) || defined(MPCQP_TIMELINE)   // (-DMPCQP_TIMELINE alone: the per-QP timeline without the phase stamps' atomics)
 __device__ unsigned long long g_timeline[65536 * 3];
    // per QP: start tick, end tick, (xcc << 32 | hw_id): who ran it and when
+#endif
+#ifdef MPCQP_STAMPS
+__device__ unsigned long long g_stamps[32];
 #define STAMP_INIT unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_t1;
 #define STAMP(i)                                                       \
   do {                                                                 \
@@ -52,6 +54,7 @@ struct DevCfg {
   int hard_x10;         // wrench engine: first-block length of a QP the early rho check flags, in tenths of the normal first block
   int last_patience;    // wrench engine: patience of a round that nothing follows (0: unlimited)
   int refine_admm;      // all-fp64 ADMM without polish at tolerances below 1e-6: one refinement step per linear solve
+  int accel_p;          // Anderson acceleration of the ADMM blocks: an extrapolation every accel_p iterations (0: off)
 };
 
 // Sum over the 8 lanes of a leg group with DPP lane moves (no LDS crossbar): quad butterfly, then half-row mirror.
@@ -90,6 +93,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// Lane move with a row mask (rows outside the mask and invalid sources read zero).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_mov_rows(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+}
+// Sum over the 64 lanes of a full wave, as a wave-uniform value (scalar register): butterfly inside each row of 16, the four row sums
+// folded with row_bcast15 / row_bcast31 into row 3, one v_readlane.  Seven vector instructions per value.
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror: every lane of a row holds the row's sum
+  v += dpp_mov_rows<0x142, 0xA>(v);   // row_bcast15 into rows 1, 3: rows 0+1, 2+3
+  v += dpp_mov_rows<0x143, 0xC>(v);   // row_bcast31 into rows 2, 3: row 3 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // Workgroup-wide max of Q floats; every thread gets the result.  NaN-propagating via the isnan flag in slot Q-1
 // is the caller's business.  Two barriers.
 template <int Q, int NW>
@@ -105,6 +125,25 @@ __device__ __forceinline__ void block_max(float (&v)[Q], float* red, int tid) {
   for (int q = 0; q < Q; ++q) {
     float m = red[q];
     for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w * 4 + q]);
+    v[q] = m;
+  }
+  __syncthreads();
+}
+
+// Workgroup-wide sum of Q floats (Q <= 12; `red` holds NW * 12 floats); every thread gets the result.  Two barriers.
+template <int Q, int NW>
+__device__ __forceinline__ void block_sum(float (&v)[Q], float* red, int tid) {
+#pragma unroll
+  for (int q = 0; q < Q; ++q) v[q] = wave_sum(v[q]);
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) red[(tid >> 6) * 12 + q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    float m = red[q];
+    for (int w = 1; w < NW; ++w) m += red[w * 12 + q];
     v[q] = m;
   }
   __syncthreads();

@@ -570,11 +570,16 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   // sees a clean dual residual and larger ratios than the fp32-tile one, whose dual residual carries the solve's rounding noise;
   // chosen on batches of other seeds than the bench's (tools/adapt_sweep.py).
   d.adapt_thr = cfg->adapt_thr > 0 ? cfg->adapt_thr : (cfg->precision == MPCQP_PREC_F64 ? 15.f : (cfg->N > 10 ? 10.f : 6.f));
+  // Anderson acceleration of the ADMM blocks (mpcqp_wrench.h): with the polish only -- an ADMM-only run stays OSQP's algorithm 1.
+  // The dense engine runs it in the fp32 iterations at horizon 10 (elsewhere the history does not fit next to the tile).
+  d.accel_p = !(cfg->flags & MPCQP_FLAG_POLISH) ? 0 : (cfg->accel > 0 ? cfg->accel : (cfg->accel < 0 ? 0 : 5));
+  const bool accel_n10 = d.accel_p > 0 && N == 10 && cfg->precision != MPCQP_PREC_F64;
   // A cold solve's first ADMM block is 0.7 check_every long: most QPs have their active set by then (mean iterations 114 -> 82 at
   // N = 10, B = 65 536: 14.6 -> 16.2 M QP/s, N = 20: +10 %), the others go on in full blocks; at B = 4096, where the launch is as
   // long as its hardest QPs, neutral (eight batches of other seeds, tools/adapt_sweep.py).  With the polish only: an ADMM-only
   // run keeps OSQP's uniform check interval.
-  d.first_block = cfg->first_block > 0 ? cfg->first_block : (cfg->first_block < 0 ? 0 : ((cfg->flags & MPCQP_FLAG_POLISH) ? (7 * cfg->check_every) / 10 : 0));
+  // With the acceleration the active set is there sooner: 0.6 check_every (tools/accel_sweep.py, profiles/r03_accel_sweep.txt).
+  d.first_block = cfg->first_block > 0 ? cfg->first_block : (cfg->first_block < 0 ? 0 : ((cfg->flags & MPCQP_FLAG_POLISH) ? ((accel_n10 ? 6 : 7) * cfg->check_every) / 10 : 0));
   d.incr_legs = cfg->incr_legs > 0 ? (cfg->incr_legs < MPCQP_W_INCR_LEGS ? cfg->incr_legs : MPCQP_W_INCR_LEGS) : (cfg->incr_legs < 0 ? 0 : MPCQP_W_INCR_LEGS);
   e->listed_max = cfg->listed_max > 0 ? cfg->listed_max : (cfg->listed_max < 0 ? 0 : 4);
   d.patience = cfg->polish_patience > 0 ? cfg->polish_patience : POLISH_PATIENCE;
@@ -585,7 +590,9 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   // the bench's, tools/patience_sweep.py, profiles/r03_hard_block_sweep.txt: x2 / x2.5 / x3 / x3.5 -> 8.62 / 8.63 / 9.15 / 9.13 M QP/s on
   // their mean at B = 4096: fewer of them need a third round, and the launch is as long as its longest QP; B = 65 536 pays 3 % for the
   // extra iterations).  Horizon 20 keeps x2 (not re-swept).
-  d.hard_x10 = cfg->hard_block_x10 > 0 ? cfg->hard_block_x10 : (N > 10 ? 10 * HARD_ITER_FACTOR : 30);
+  // With the acceleration the longer block buys nothing (x1 / x1.5 / x2 / x3: same held-out mean within run-to-run spread, the large
+  // batch fastest at x1): a flagged QP gets the larger penalty and the normal block.
+  d.hard_x10 = cfg->hard_block_x10 > 0 ? cfg->hard_block_x10 : (N > 10 ? 10 * HARD_ITER_FACTOR : (accel_n10 ? 10 : 30));
   // The round that nothing follows (iteration cap reached) used to run its whole polish budget; it now gives up after four steps that
   // fail to halve the KKT violation (horizon 10: 9.04 -> 9.35 M on the held-out mean, the same QPs solved, profiles/r03_last_patience_sweep.txt)
   d.last_patience = cfg->polish_last_patience > 0 ? cfg->polish_last_patience : (cfg->polish_last_patience < 0 || N > 10 ? 0 : 4);
@@ -890,7 +897,7 @@ int mpcqp_last_kernel_ms(mpcqp_handle h, float* ms) {
   return MPCQP_OK;
 }
 
-#ifdef MPCQP_STAMPS
+#if defined(MPCQP_STAMPS) || defined(MPCQP_TIMELINE)
 extern "C" int mpcqp_debug_read_timeline(unsigned long long* out, int64_t B) {
   if (B > 65536) return MPCQP_EINVAL;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)B * 3 * sizeof(unsigned long long)) == hipSuccess ? MPCQP_OK : MPCQP_EHIP;

@@ -62,6 +62,7 @@ struct SmemS {
   alignas(16) double Tc[6 * 144];
   alignas(16) double cmb[8 * 12];
   float red[SG_NW * 4];
+  float aared[SG_NW * 12];             // Anderson acceleration: the waves' partial inner products
   float kkt[4], resid[4];
   float gmax, rho, ratio;
   int iters, psteps, hard, bad;
@@ -836,7 +837,7 @@ __device__ __forceinline__ int sg_warm_start(SmemS& s, SLeg& Lg, const TIO* __re
 // check of a cold solve's first block.  Updates s.rho / s.iters / s.hard and the lane's iterate (ua, za, ya) and polish start (pu, py).
 template <typename TM>
 __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, double* __restrict__ ws, const int adapt, const int kfirst,
-                                        const int N, const int tid) {
+                                        const int N, const int tid, const bool aa_on) {
   float rho = s.rho;
   int K = kfirst > 0 ? min(kfirst, cfg.check_every) : cfg.check_every;
   K = max(1, min(K, cfg.max_iter - s.iters));
@@ -859,7 +860,23 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
     for (int i = 0; i < 5; ++i) { z[i] = Lg.za[i]; yh[i] = Lg.ya[i] / r; }
     const double lo0 = Lg.stance ? s.fmin : 0.0, hi0 = Lg.stance ? s.fmax : 0.0, loA = Lg.stance ? -BIG : 0.0, hiB = Lg.stance ? BIG : 0.0;
     bool rebuild = false;
+    // Anderson acceleration of the block (mpcqp_wrench.h: w_aa_step; with the polish only): an iteration costs two recursions of N
+    // steps here, an extrapolation nine workgroup-wide sums -- a few per cent of the block for the iterations it saves.  In a cold
+    // solve's FIRST block only: at N = 60 the later rounds of the few QPs that need them ended in polish rounds of up to 98 steps with
+    // it (a refactorisation each; profiles/r03_stage_accel.txt), while the first block is where the logged ticks of the reference's
+    // run are all solved.  The period must divide the early rho check's iteration (25): a check that comes one or two iterations
+    // after an extrapolation sees a distorted residual ratio and flags most QPs (periods 4 and 6: 40 % slower)
+    const int aa_p = aa_on ? cfg.accel_p : 0;
+    LegAA aa;
+    double aa_xb[5], aa_fp[5];
     for (;;) {
+      bool aa_have = false;
+      int aa_left = aa_p;
+      if (aa_p > 0) {
+        w_aa_reset(aa);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { aa_xb[k] = z[k] + yh[k]; aa_fp[k] = aa_xb[k]; }
+      }
       for (; it < seg_end; ++it) {
         double v[5];
 #pragma unroll
@@ -891,6 +908,22 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
           const double zn = fmin(fmax(t, lo), hi);
           yh[k] = t - zn;
           z[k] = zn;
+        }
+        if (aa_p > 0 && --aa_left == 0) {   // uniform
+          aa_left = aa_p;
+          if (it + 1 < seg_end) {           // (the block's last iterate is a genuine ADMM iterate: the polish starts from it)
+            double fx[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) fx[k] = z[k] + yh[k];
+            w_aa_step<double, SG_NW>(aa, aa_xb, aa_fp, fx, aa_have, Lg.leg, s.aared, tid);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              const double lo = k == 0 ? lo0 : ((k & 1) ? loA : 0.0), hi = k == 0 ? hi0 : ((k & 1) ? 0.0 : hiB);
+              const double zn = fmin(fmax(aa_xb[k], lo), hi);
+              yh[k] = aa_xb[k] - zn;
+              z[k] = zn;
+            }
+          }
         }
       }
       STAMP(2);
@@ -1163,7 +1196,8 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
       int budget = kind == R_WARM ? min(warm_tries, polish_max) : 2 * polish_max;
       if (kind == R_ADMM) {
         // (a warm start from remembered (u, y): a first block 0.6 of the cold one, as in the dense engine)
-        sg_admm<TM>(s, cfg, Lg, ws, round == 0 ? 1 : 0, round == 0 ? (warm >= 2 ? max(1, (6 * (cfg.first_block > 0 ? cfg.first_block : cfg.check_every)) / 10) : cfg.first_block) : 0, N, tid);
+        sg_admm<TM>(s, cfg, Lg, ws, round == 0 ? 1 : 0, round == 0 ? (warm >= 2 ? max(1, (6 * (cfg.first_block > 0 ? cfg.first_block : cfg.check_every)) / 10) : cfg.first_block) : 0, N, tid,
+                    round == 0);   // (the acceleration: in the first block only, see sg_admm)
         budget = admm_only ? 0 : (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
       }
       const bool last = kind != R_ADMM || s.iters >= max_iter;

@@ -68,6 +68,7 @@ struct SmemW {
   alignas(16) double piv[2 * Geo::DP];                   // pivot-row broadcast (TM-typed view)
   alignas(16) double bv[Geo::DP], cv[Geo::DP];           // mat-vec in / out (TM-typed view)
   float red[Geo::NW * 4];
+  float aared[Geo::NW * 12];     // Anderson acceleration: partial inner products of the waves (four waves per QP)
   float kkt[4];
   float resid[4];                // residuals of the last ADMM iterate that w_ratio looked at
   float gmax, rho, ratio;
@@ -117,6 +118,16 @@ __device__ __forceinline__ void wmax(float (&v)[Q], float* red, int tid) {
     for (int q = 0; q < Q; ++q) v[q] = wave_max(v[q]);
   } else {
     block_max<Q, NW>(v, red, tid);
+  }
+}
+
+template <int Q, int NW>
+__device__ __forceinline__ void wsum(float (&v)[Q], float* red, int tid) {
+  if constexpr (NW == 1) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = wave_sum(v[q]);
+  } else {
+    block_sum<Q, NW>(v, red, tid);
   }
 }
 
@@ -769,6 +780,106 @@ constexpr int POLISH_PATIENCE = MPCQP_W_POLISH_PATIENCE;   // polish steps that 
 #define MPCQP_W_ADAPT_AT 25
 #endif
 
+// ----------------------------------------------------------------------------------------------------- Anderson acceleration
+// The ADMM block exists to find the active set, and on the QPs that end a launch (two-legged support at low friction) plain
+// ADMM needs 300 - 400 iterations for it: the iteration is a contraction with a factor close to 1 along a few directions.
+// Anderson acceleration (type II, memory AA_M) of the map  v -> f^p(v),  v = z + y / rho  the pre-projection variable of
+// OSQP's iteration (z = clip(v), y / rho = v - z: the five rows of a leg-stage, five numbers per lane):  every p-th iterate is
+// replaced by the combination of the last AA_M + 1 of them that minimises the fixed-point residual in the least-squares sense,
+//     gam = argmin | r - dF gam |,   v+ = f(v) - dX gam,     dF / dX: differences of consecutive residuals / images
+// -- nine inner products over the wave (seven DPP steps each), a regularised 3 x 3 solve in uniform registers, fifteen FMAs per
+// lane, once per p iterations.  numpy study on the condensed QP (tools/accel_study.py): the hardest QPs of five batches reach a
+// polishable iterate in half the iterations (worst case of a batch 375 -> 250 us of solve), the easy ones are unchanged.
+// Only with the polish (MPCQP_FLAG_POLISH): an ADMM-only run is OSQP's algorithm 1 unchanged.  History in fp32 (it steers an
+// extrapolation, it is not part of the answer); base point and images in the iteration's element type.
+#ifndef MPCQP_AA_M
+#define MPCQP_AA_M 3
+#endif
+constexpr int AA_M = MPCQP_AA_M;
+struct LegAA {
+  float rp[5];                       // previous residual f(v) - v
+  float dX[AA_M][5], dF[AA_M][5];    // column AA_M - 1 is the newest
+};
+
+__device__ __forceinline__ void w_aa_reset(LegAA& h) {
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    h.rp[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < AA_M; ++j) { h.dX[j][k] = 0.f; h.dF[j][k] = 0.f; }
+  }
+}
+
+// One extrapolation: fx = f^p(xb) has just been computed.  Files (fx, fx - xb) in the history and returns the next base point in
+// xb (the extrapolated iterate, or fx itself while the history is empty / when the least-squares problem is degenerate -- then the
+// history restarts).  `have_prev`: an earlier image exists (uniform).  Uniform control flow; ends with the caller's state untouched
+// except xb / fp / h.
+template <typename TM, int NW>
+__device__ __forceinline__ void w_aa_step(LegAA& h, TM (&xb)[5], TM (&fp)[5], const TM (&fx)[5], bool& have_prev, const bool leg,
+                                          float* __restrict__ red, const int tid) {
+  static_assert(AA_M == 3 || AA_M == 2, "the solve below is written for two or three columns");
+  constexpr int M = AA_M, NQ_ = M * (M + 1) / 2 + M;
+  float r[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    r[k] = leg ? (float)(fx[k] - xb[k]) : 0.f;
+    const float dx = have_prev ? (float)(fx[k] - fp[k]) : 0.f, df = have_prev ? r[k] - h.rp[k] : 0.f;
+#pragma unroll
+    for (int j = 0; j + 1 < M; ++j) { h.dX[j][k] = h.dX[j + 1][k]; h.dF[j][k] = h.dF[j + 1][k]; }
+    h.dX[M - 1][k] = dx; h.dF[M - 1][k] = df;
+    fp[k] = fx[k]; h.rp[k] = r[k];
+  }
+  have_prev = true;
+  float q[NQ_];   // M = 3: 00 01 02 11 12 22 | 0r 1r 2r;  M = 2: 00 01 11 | 0r 1r
+#pragma unroll
+  for (int i = 0; i < NQ_; ++i) q[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    int at = 0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+#pragma unroll
+      for (int j = i; j < M; ++j) { q[at] = fmaf(h.dF[i][k], h.dF[j][k], q[at]); ++at; }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) { q[at] = fmaf(h.dF[i][k], r[k], q[at]); ++at; }
+  }
+  wsum<NQ_, NW>(q, red, tid);
+  float g[M];
+  bool ok;
+  if constexpr (M == 3) {
+    const float tr = q[0] + q[3] + q[5];
+    const bool have = tr > 0.f;
+    const float reg = 1e-6f * tr + 1e-30f;
+    // regularised normal equations by L D L' (uniform values)
+    const float a00 = q[0] + reg, a11 = q[3] + reg, a22 = q[5] + reg, a01 = q[1], a02 = q[2], a12 = q[4];
+    const float i0 = w_rcp(a00), l10 = a01 * i0, l20 = a02 * i0;
+    const float d1 = fmaf(-l10, a01, a11), i1 = w_rcp(d1), t21 = fmaf(-l20, a01, a12), l21 = t21 * i1;
+    const float d2 = fmaf(-l21, t21, fmaf(-l20, a02, a22)), i2 = w_rcp(d2);
+    const float y0 = q[6], y1 = fmaf(-l10, y0, q[7]), y2 = fmaf(-l21, y1, fmaf(-l20, y0, q[8]));
+    g[2] = y2 * i2; g[1] = fmaf(-l21, g[2], y1 * i1); g[0] = fmaf(-l20, g[2], fmaf(-l10, g[1], y0 * i0));
+    ok = have && d1 > 0.f && d2 > 0.f && fabsf(g[0]) + fabsf(g[1]) + fabsf(g[2]) <= 1e4f;   // (a NaN fails the comparison)
+    if (!have) have_prev = true; else if (!ok) { w_aa_reset(h); have_prev = false; }   // degenerate history: start again from this iterate
+  } else {
+    const float tr = q[0] + q[2];
+    const bool have = tr > 0.f;
+    const float reg = 1e-6f * tr + 1e-30f;
+    const float a00 = q[0] + reg, a11 = q[2] + reg, a01 = q[1];
+    const float i0 = w_rcp(a00), l10 = a01 * i0, d1 = fmaf(-l10, a01, a11), i1 = w_rcp(d1);
+    const float y0 = q[3], y1 = fmaf(-l10, y0, q[4]);
+    g[1] = y1 * i1; g[0] = fmaf(-l10, g[1], y0 * i0);
+    ok = have && d1 > 0.f && fabsf(g[0]) + fabsf(g[1]) <= 1e4f;
+    if (have && !ok) { w_aa_reset(h); have_prev = false; }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    float c = 0.f;
+#pragma unroll
+    for (int j = 0; j < M; ++j) c = fmaf(g[j], h.dX[j][k], c);
+    xb[k] = ok ? fx[k] - (TM)c : fx[k];
+  }
+}
+
 // The leg's 6 x 3 wrench map [B_l ; contact / m I] and the inverse diagonal of D = 2 alpha + sigma + rho G'G.
 template <typename TV, typename TM, int N>
 __device__ __forceinline__ void w_admm_sys(const SmemW<TV, N>& s, const DevCfg& cfg, int L, float rho, LegSys<TM>& Ls) {
@@ -854,8 +965,21 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
       A.lo0 = stance ? (TM)s.fmin : (TM)0; A.hi0 = stance ? (TM)s.fmax : (TM)0;
       A.loA = stance ? -BIG : (TM)0; A.hiB = stance ? BIG : (TM)0;
       bool rebuild = false;
+      // Anderson acceleration (with the polish only): history per segment of iterations with the same matrix
+      // (fp32 iterations at horizon 10 for now: next to an fp64 iteration tile or the horizon-20 tile the history spills)
+      constexpr bool AA_ON = !REFINE && sizeof(TM) == 4 && N <= 10;
+      const int aa_p = AA_ON ? __builtin_amdgcn_readfirstlane(cfg.accel_p) : 0;
+      LegAA aa;
+      TM aa_xb[5], aa_fp[5];
       for (;;) {   // segments of iterations with the same matrix; the early rho check sits between the first two
         const int n_it = __builtin_amdgcn_readfirstlane(seg_end - it);
+        bool aa_have = false;
+        int aa_left = aa_p;
+        if (aa_p > 0) {
+          w_aa_reset(aa);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) { aa_xb[k] = A.z[k] + A.yh[k]; aa_fp[k] = aa_xb[k]; }
+        }
         for (int i = 0; i < n_it; ++i) {
           // rhs = sigma u - g + rho G'(z - yh)
           TM v[5];
@@ -899,6 +1023,22 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
             const TM zn = fmin(fmax(t, lo), hi);
             A.yh[k] = t - zn;
             A.z[k] = zn;
+          }
+          if (aa_p > 0 && --aa_left == 0) {   // uniform
+            aa_left = aa_p;
+            if (i + 1 < n_it) {               // (the block's last iterate is a genuine ADMM iterate: the polish starts from it)
+              TM fx[5];
+#pragma unroll
+              for (int k = 0; k < 5; ++k) fx[k] = A.z[k] + A.yh[k];
+              w_aa_step<TM, NW>(aa, aa_xb, aa_fp, fx, aa_have, leg, s.aared, tid);
+#pragma unroll
+              for (int k = 0; k < 5; ++k) {
+                const TM lo = k == 0 ? A.lo0 : ((k & 1) ? A.loA : (TM)0), hi = k == 0 ? A.hi0 : ((k & 1) ? (TM)0 : A.hiB);
+                const TM zn = fmin(fmax(aa_xb[k], lo), hi);
+                A.yh[k] = aa_xb[k] - zn;
+                A.z[k] = zn;
+              }
+            }
           }
         }
         it = seg_end;
@@ -1403,7 +1543,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       }
       b = (size_t)__builtin_amdgcn_readfirstlane(ob.list[(size_t)cls * ob.cap + at]);
     }
-#ifdef MPCQP_STAMPS
+#if defined(MPCQP_STAMPS) || defined(MPCQP_TIMELINE)
     const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();   // the 100 MHz constant clock: comparable across CUs and XCDs
 #endif
 #ifdef MPCQP_LDS_POISON   // diagnostic build: every QP starts from an LDS block full of NaN patterns (finds reads of stale LDS)
@@ -1513,7 +1653,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       ++round;
     }
     w_output<TV, TIO, N>(s, tabs, ug, Xg, statusg, itersg, resg, in.y_state, b, ok, fresh_tid<NW>(tid0));
-#ifdef MPCQP_STAMPS
+#if defined(MPCQP_STAMPS) || defined(MPCQP_TIMELINE)
     if (tid == 0 && b < 65536) {
       unsigned hw, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));

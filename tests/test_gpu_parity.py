@@ -219,6 +219,48 @@ def test_inverse_updates_give_the_rebuilds_answers():
         assert rel_err(upd["u"], reb["u"]).max() <= 1e-8, rel_err(upd["u"], reb["u"]).max()
 
 
+def test_anderson_acceleration_changes_the_path_not_the_optimum(oracle_solve):
+    """MpcQpConfig.accel: the ADMM iterate is extrapolated every fifth iteration from its last three (mpcqp_wrench.h: w_aa_step;
+    stage-wise engine: the same routine with workgroup-wide sums).  It decides how soon the active set is found, nothing else: with it
+    and without it every QP is solved, both answers are within 1e-4 of the oracle's optimum and within 1e-6 of each other -- and on
+    the slowly converging QPs (two-legged support at low friction) it needs fewer iterations."""
+    b = mpcqp.synth.config3(1024)
+    ref = oracle_solve(b)
+    on = gpu_solve(b, io="f64", precision="mixed")                      # default: accel = 5
+    off = gpu_solve(b, io="f64", precision="mixed", accel=-1)
+    for o in (on, off):
+        ok = solved(o["status"])
+        assert ok.mean() >= 0.999
+        assert rel_err(o["u"], ref["u"])[ok].max() <= 1e-4
+    both = solved(on["status"]) & solved(off["status"])
+    assert rel_err(on["u"], off["u"])[both].max() <= 1e-6, rel_err(on["u"], off["u"])[both].max()
+    it_on, it_off = on["iters"] % 1000, off["iters"] % 1000
+    assert not np.array_equal(it_on, it_off)                            # (the switch does something)
+    hard = it_off >= 200                                                # what the plain iteration needs three blocks and more for
+    assert hard.sum() >= 5 and it_on[hard].mean() < 0.8 * it_off[hard].mean(), (hard.sum(), it_on[hard].mean(), it_off[hard].mean())
+    assert it_on.max() <= it_off.max()
+    # the stage-wise engine at the same horizon (its ADMM state lives in one lane per leg-stage; the sums cross four waves)
+    bs = {k: (v[:128] if isinstance(v, np.ndarray) and len(v) == 1024 else v) for k, v in b.items()}
+    s_on = gpu_solve(bs, io="f64", precision="mixed", flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_STAGE_KERNEL)
+    s_off = gpu_solve(bs, io="f64", precision="mixed", flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_STAGE_KERNEL, accel=-1)
+    for o in (s_on, s_off):
+        ok = solved(o["status"])
+        assert ok.mean() >= 0.99
+        assert rel_err(o["u"], ref["u"][:128])[ok].max() <= 1e-4
+    assert not np.array_equal(s_on["iters"], s_off["iters"])
+
+
+def test_anderson_acceleration_leaves_admm_only_runs_alone():
+    """Without MPCQP_FLAG_POLISH the engine is OSQP's algorithm 1 (what the reference runs, src/mpc.py:51-55), whatever `accel` says:
+    same bits with the field at its default, at 5 and at -1."""
+    b = mpcqp.synth.config3(256)
+    runs = [gpu_solve(b, io="f64", precision=prec, flags=0, max_iter=300, eps_abs=1e-4, eps_rel=1e-4, **kw)
+            for prec in ("mixed", "f64") for kw in ({}, {"accel": 5}, {"accel": -1})]
+    for k in (1, 2):
+        assert np.array_equal(runs[0]["u"], runs[k]["u"]) and np.array_equal(runs[0]["iters"], runs[k]["iters"])
+        assert np.array_equal(runs[3]["u"], runs[3 + k]["u"]) and np.array_equal(runs[3]["iters"], runs[3 + k]["iters"])
+
+
 def test_no_timing_flag(oracle_solve):
     """MPCQP_FLAG_NO_TIMING: same results, no event pair around the solve, mpcqp_last_kernel_ms refuses."""
     b = mpcqp.synth.config3(64)

@@ -1,0 +1,55 @@
+"""Developer study: Anderson acceleration of the ADMM blocks (MpcQpConfig.accel; mpcqp_wrench.h) against the plain iteration --
+period, first-block length and the block factor of QPs the early rho check flags.  Bench seed + six other seeds at B = 4096, and
+B = 65 536.  Also checks every accelerated answer against the plain engine's (both polished optima: they must agree to 1e-6).
+usage: python tools/accel_sweep.py [accel,first_block,hard_block_x10,check_every ...]"""
+import os, sys
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import mpcqp
+if os.environ.get("AS_LIB"):   # a variant build of the library (e.g. -DMPCQP_AA_M=2)
+    from mpcqp import _capi
+    _capi._product = _capi.Library(os.path.join(REPO, "mpc-for-dynamic-locomotion-in-the-mit-cheetah-3_amd", "csrc", os.environ["AS_LIB"]))
+allg = ("trot", "pronk", "amble", "gallop")
+seeds = (20250809, 1, 2, 3, 4, 5, 6)
+batches = {sd: mpcqp.synth.make_batch(4096, 10, 0.03, sd, allg, (0.3, 0.5, 0.7, 1.0)) for sd in seeds}
+big = mpcqp.synth.config4(65536)
+combos = [(-1, 0, 0, 100), (5, 0, 0, 100), (4, 0, 0, 100), (6, 0, 0, 100), (8, 0, 0, 100), (5, 50, 0, 100), (5, 60, 0, 100), (5, 0, 20, 100), (5, 50, 20, 100), (5, 0, 0, 70)]
+if len(sys.argv) > 1:
+    combos = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
+ref_u = {}
+for ac, fb, hx, ce in combos:
+    sol = mpcqp.MPCBatch(N=10, precision="mixed", accel=ac, first_block=fb, hard_block_x10=hx, check_every=ce, flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)
+    line = f"accel {ac:2d} first_block {fb:3d} hard_x10 {hx:2d} check_every {ce:3d}:"
+    rates = []
+    for sd in seeds:
+        dev = sol.upload(batches[sd])
+        for _ in range(3):
+            out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ms = []
+        for _ in range(15):
+            ev[0].record(); out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"]); ev[1].record()
+            torch.cuda.synchronize(); ms.append(ev[0].elapsed_time(ev[1]))
+        it = out["iters"].cpu().numpy(); st = out["status"].cpu().numpy(); u = out["u"].cpu().numpy().astype(np.float64).reshape(4096, -1)
+        dmax = 0.0
+        if sd in ref_u:
+            both = (st == 1) & ref_u[sd][1]
+            dmax = float((np.abs(u - ref_u[sd][0]).max(axis=1) / np.maximum(np.abs(ref_u[sd][0]).max(axis=1), 1.0))[both].max())
+        else:
+            ref_u[sd] = (u, st == 1)
+        m = float(np.median(ms)); rates.append(4096 / m / 1e3)
+        line += f" | {sd % 100000}: {m * 1e3:.0f}us uns {int((st != 1).sum())} it {(it % 1000).mean():.0f}/{(it % 1000).max()} ps {(it // 1000).mean():.2f}/{(it // 1000).max()} d {dmax:.0e}"
+    dev = sol.upload(big)
+    for _ in range(2):
+        out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ms = []
+    for _ in range(5):
+        ev[0].record(); out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"]); ev[1].record()
+        torch.cuda.synchronize(); ms.append(ev[0].elapsed_time(ev[1]))
+    st = out["status"].cpu().numpy(); it = out["iters"].cpu().numpy()
+    print(line + f" || mean of other seeds {np.mean(rates[1:]):.2f} M, bench seed {rates[0]:.2f} M | B=65536: {65536 / np.median(ms) / 1e3:.2f} M uns {int((st != 1).sum())} it {(it % 1000).mean():.0f}", flush=True)
+    del sol

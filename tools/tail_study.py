@@ -7,16 +7,16 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import mpcqp
 from mpcqp import _capi
-lib = _capi.Library(os.path.join(REPO, "mpc-for-dynamic-locomotion-in-the-mit-cheetah-3_amd", "csrc", "libmpcqp_stamps.so"))
+lib = _capi.Library(os.path.join(REPO, "mpc-for-dynamic-locomotion-in-the-mit-cheetah-3_amd", "csrc", os.environ.get("TL_LIB", "libmpcqp_stamps.so")))   # TL_LIB=libmpcqp_timeline.so: the timeline without the phase stamps
 _capi._product = lib
 B = int(os.environ.get("TL_B", "4096"))
 TICK = 100.0   # s_memtime ticks per us (100 MHz constant clock on gfx950)
 names = ["trot", "pronk", "amble", "gallop"]
 allg = ("trot", "pronk", "amble", "gallop")
 lib.lib.mpcqp_debug_read_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int64]
-for seed in (20250809, 1, 2, 3, 4):
+for seed in [int(x) for x in os.environ.get('TL_SEEDS', '20250809,1,2,3,4').split(',')]:
     batch = mpcqp.synth.make_batch(B, 10, 0.03, seed, allg, (0.3, 0.5, 0.7, 1.0))
-    sol = mpcqp.MPCBatch(N=10, precision="mixed")
+    sol = mpcqp.MPCBatch(N=10, precision="mixed", accel=int(os.environ.get("TL_ACCEL", "0")), first_block=int(os.environ.get("TL_FIRST", "0")), hard_block_x10=int(os.environ.get("TL_HARD", "0")))
     dev = sol.upload(batch)
     for _ in range(3):
         out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])

@@ -1,0 +1,31 @@
+"""Diagnostic (timeline build, make -C csrc timeline): per-QP start / end ticks, iteration and polish-step counts of launches of 4096
+on several seeds -> gpurun_out/<TL_OUT>.npz, analysed offline for the dispatch-order model (the batches are regenerated from their seeds).
+env: TL_ACCEL / TL_FIRST / TL_HARD (engine tuning fields), TL_SEEDS, TL_OUT."""
+import ctypes, os, sys
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import mpcqp
+from mpcqp import _capi
+lib = _capi.Library(os.path.join(REPO, "mpc-for-dynamic-locomotion-in-the-mit-cheetah-3_amd", "csrc", "libmpcqp_timeline.so"))
+_capi._product = lib
+lib.lib.mpcqp_debug_read_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+allg = ("trot", "pronk", "amble", "gallop")
+B = 4096
+recs = {}
+flags = mpcqp.FLAG_POLISH | (mpcqp.FLAG_NATURAL_ORDER if os.environ.get("TL_NATURAL") else 0)
+for seed in [int(x) for x in os.environ.get("TL_SEEDS", "20250809,1,2,3,4,5,6,7").split(",")]:
+    batch = mpcqp.synth.make_batch(B, 10, 0.03, seed, allg, (0.3, 0.5, 0.7, 1.0))
+    sol = mpcqp.MPCBatch(N=10, precision="mixed", accel=int(os.environ.get("TL_ACCEL", "0")), first_block=int(os.environ.get("TL_FIRST", "0")),
+                         hard_block_x10=int(os.environ.get("TL_HARD", "0")), flags=flags)
+    dev = sol.upload(batch)
+    for _ in range(3):
+        out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * (3 * B))()
+    assert lib.lib.mpcqp_debug_read_timeline(buf, B) == 0
+    t = np.array(list(buf), dtype=np.uint64).reshape(B, 3)
+    recs[f"t_{seed}"] = t; recs[f"iters_{seed}"] = out["iters"].cpu().numpy(); recs[f"ms_{seed}"] = np.float64(sol.last_kernel_ms())
+    print(seed, sol.last_kernel_ms(), flush=True)
+    del sol
+np.savez_compressed(os.path.join(REPO, "gpurun_out", os.environ.get("TL_OUT", "timeline_dump") + ".npz"), **recs)
