@@ -110,15 +110,15 @@ typedef struct MpcQpConfig {
   int32_t max_iter;     /* ADMM iteration cap K */
   int32_t check_every;  /* ADMM block length between polish attempts (iterations); default 100, tuned for N = 10 --
                            scale both with N / 10 for other horizons (200 / 800 at N = 20), as the Python host layer does.
-                           With MPCQP_FLAG_POLISH a cold solve's first block is 0.7 check_every long (most QPs have their active
-                           set by then); ADMM-only runs test termination every check_every iterations, as OSQP does */
+                           With MPCQP_FLAG_POLISH a cold solve's first block is 0.6 check_every long (0.7 without `accel`; most QPs have
+                           their active set by then); ADMM-only runs test termination every check_every iterations, as OSQP does */
   double eps_abs, eps_rel;
   int32_t polish_max;   /* active-set refinement steps per polish attempt */
   int32_t device;       /* HIP device ordinal (product library) */
   /* Engine tuning (product library; the checker ignores them).  0 = the engine's own default, which is what the benchmark runs
      with; none of them changes a result beyond rounding except alpha_floor.  They exist for the measurement scripts under tools/
      and for the tests that compare a mechanism with its fallback -- the library reads no environment variables. */
-  int32_t first_block;  /* iterations of a cold solve's first ADMM block; 0: 0.7 check_every (ADMM-only runs: check_every); -1: check_every */
+  int32_t first_block;  /* iterations of a cold solve's first ADMM block; 0: 0.6 check_every (0.7 without `accel`; ADMM-only runs: check_every); -1: check_every */
   int32_t incr_legs;    /* changed leg-stages up to which a polish step updates S^-1 instead of rebuilding it; 0: 8; -1: always rebuild */
   int32_t listed_max;   /* device-fills up to which an ordered launch is one workgroup per QP (beyond: resident workgroups on a queue);
                            0: 4; -1: always queued */
@@ -128,13 +128,16 @@ typedef struct MpcQpConfig {
   int32_t polish_cheap_steps; /* ... and the further steps a round may take beyond that as long as each only UPDATES S^-1 on at most
                                  polish_cheap_legs changed leg-stages; 0: default, -1: none */
   int32_t polish_cheap_legs;  /* 0: default */
-  int32_t hard_block_x10;     /* a QP that the early rho check flags gets a first block this many TENTHS of first_block long; 0: default */
+  int32_t hard_block_x10;     /* a QP that the early rho check flags gets a first block this many TENTHS of first_block long; 0: default
+                                 (10 with `accel` at N = 10: the larger penalty, the normal block; 30 without; 20 at N = 20) */
   int32_t polish_last_patience; /* the polish patience of a round that nothing follows (iteration cap reached); 0: default (unlimited: the
                                    round uses its whole budget at N = 20, 4 at N = 10), n > 0: gives up after n steps that fail to halve the KKT violation,
                                    -1: unlimited */
   int32_t accel;        /* Anderson acceleration of the ADMM blocks (with MPCQP_FLAG_POLISH only; an ADMM-only run is OSQP's algorithm 1
-                           unchanged): an extrapolation of the ADMM iterate every `accel` iterations from the last three; 0: default (5),
-                           -1: off.  Changes the path to the optimum (fewer iterations on slowly converging QPs), not the optimum */
+                           unchanged): an extrapolation of the ADMM iterate every `accel` iterations from the last four; 0: default (5),
+                           -1: off.  Periods that do not divide the early rho check's iteration (25) distort that check: use 5.  Changes
+                           the path to the optimum (fewer iterations on slowly converging QPs), not the optimum.  MIXED arithmetic in
+                           the dense engine (all-fp64 iterations run without it); a cold solve's first block in the stage-wise engine */
 } MpcQpConfig;
 
 typedef struct mpcqp_engine* mpcqp_handle;

@@ -329,8 +329,11 @@ hipError_t launch_wrench(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void
     }
   }
   const WrTabs tabs = {e->wr_K, e->wr_kinv32, e->wr_kinv64};
+#ifndef MPCQP_DIAG_LDSPAD   // (diagnostic builds only: dynamic LDS that limits the resident workgroups per CU, tools/occupancy_study.sh)
+#define MPCQP_DIAG_LDSPAD 0
+#endif
   if (e->cfg.precision == MPCQP_PREC_MIXED)
-    hipLaunchKernelGGL((mpcqp_wrench_solve<double, float, double, TIO, N>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
+    hipLaunchKernelGGL((mpcqp_wrench_solve<double, float, double, TIO, N>), grid, dim3(WG<N>::NT), MPCQP_DIAG_LDSPAD, s, e->dcfg, tabs, in, (TIO*)u,
                        (TIO*)X, st, it, res, ob, (int)B);
   else if (e->dev.refine_admm)   // tight-tolerance ADMM-only runs: the instantiation with a refinement step per linear solve
     hipLaunchKernelGGL((mpcqp_wrench_solve<double, double, double, TIO, N, true>), grid, dim3(WG<N>::NT), 0, s, e->dcfg, tabs, in, (TIO*)u,
@@ -571,15 +574,16 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   // chosen on batches of other seeds than the bench's (tools/adapt_sweep.py).
   d.adapt_thr = cfg->adapt_thr > 0 ? cfg->adapt_thr : (cfg->precision == MPCQP_PREC_F64 ? 15.f : (cfg->N > 10 ? 10.f : 6.f));
   // Anderson acceleration of the ADMM blocks (mpcqp_wrench.h): with the polish only -- an ADMM-only run stays OSQP's algorithm 1.
-  // The dense engine runs it in the fp32 iterations at horizon 10 (elsewhere the history does not fit next to the tile).
+  // The dense engine runs it in its fp32 iterations (MIXED; next to an fp64 iteration tile the history does not fit).
   d.accel_p = !(cfg->flags & MPCQP_FLAG_POLISH) ? 0 : (cfg->accel > 0 ? cfg->accel : (cfg->accel < 0 ? 0 : 5));
-  const bool accel_n10 = d.accel_p > 0 && N == 10 && cfg->precision != MPCQP_PREC_F64;
+  const bool accel_dense = d.accel_p > 0 && cfg->precision != MPCQP_PREC_F64 && (N == 10 || N == 20) && !(cfg->flags & MPCQP_FLAG_STAGE_KERNEL);
+  const bool accel_n10 = accel_dense && N == 10;   // (the block lengths below were swept with the acceleration on the dense engine only)
   // A cold solve's first ADMM block is 0.7 check_every long: most QPs have their active set by then (mean iterations 114 -> 82 at
   // N = 10, B = 65 536: 14.6 -> 16.2 M QP/s, N = 20: +10 %), the others go on in full blocks; at B = 4096, where the launch is as
   // long as its hardest QPs, neutral (eight batches of other seeds, tools/adapt_sweep.py).  With the polish only: an ADMM-only
   // run keeps OSQP's uniform check interval.
   // With the acceleration the active set is there sooner: 0.6 check_every (tools/accel_sweep.py, profiles/r03_accel_sweep.txt).
-  d.first_block = cfg->first_block > 0 ? cfg->first_block : (cfg->first_block < 0 ? 0 : ((cfg->flags & MPCQP_FLAG_POLISH) ? ((accel_n10 ? 6 : 7) * cfg->check_every) / 10 : 0));
+  d.first_block = cfg->first_block > 0 ? cfg->first_block : (cfg->first_block < 0 ? 0 : ((cfg->flags & MPCQP_FLAG_POLISH) ? ((accel_dense ? 6 : 7) * cfg->check_every) / 10 : 0));
   d.incr_legs = cfg->incr_legs > 0 ? (cfg->incr_legs < MPCQP_W_INCR_LEGS ? cfg->incr_legs : MPCQP_W_INCR_LEGS) : (cfg->incr_legs < 0 ? 0 : MPCQP_W_INCR_LEGS);
   e->listed_max = cfg->listed_max > 0 ? cfg->listed_max : (cfg->listed_max < 0 ? 0 : 4);
   d.patience = cfg->polish_patience > 0 ? cfg->polish_patience : POLISH_PATIENCE;

@@ -69,6 +69,7 @@ struct SmemW {
   alignas(16) double bv[Geo::DP], cv[Geo::DP];           // mat-vec in / out (TM-typed view)
   float red[Geo::NW * 4];
   float aared[Geo::NW * 12];     // Anderson acceleration: partial inner products of the waves (four waves per QP)
+  float aah[N > 10 ? 45 * Geo::NL : 1];   // ... and, at horizon 20, the leg-stages' history between extrapolations ([slot][leg-stage]; at horizon 10 it stays in registers)
   float kkt[4];
   float resid[4];                // residuals of the last ADMM iterate that w_ratio looked at
   float gmax, rho, ratio;
@@ -966,11 +967,37 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
       A.loA = stance ? -BIG : (TM)0; A.hiB = stance ? BIG : (TM)0;
       bool rebuild = false;
       // Anderson acceleration (with the polish only): history per segment of iterations with the same matrix
-      // (fp32 iterations at horizon 10 for now: next to an fp64 iteration tile or the horizon-20 tile the history spills)
-      constexpr bool AA_ON = !REFINE && sizeof(TM) == 4 && N <= 10;
+      // (fp32 iterations only: next to an fp64 iteration tile the history spills.  Horizon 10: the history lives in registers;
+      //  horizon 20: in LDS between extrapolations -- next to that tile 45 more live registers are 90 more spilled ones)
+      constexpr bool AA_ON = !REFINE && sizeof(TM) == 4, AA_LDS = N > 10;
       const int aa_p = AA_ON ? __builtin_amdgcn_readfirstlane(cfg.accel_p) : 0;
       LegAA aa;
       TM aa_xb[5], aa_fp[5];
+      auto aa_park = [&]() {      // registers -> LDS (leg lanes)
+        if constexpr (AA_LDS) {
+          if (leg) {
+            float* h = s.aah + L;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+              h[NL * k] = (float)aa_xb[k]; h[NL * (5 + k)] = (float)aa_fp[k]; h[NL * (10 + k)] = aa.rp[k];
+#pragma unroll
+              for (int j = 0; j < AA_M; ++j) { h[NL * (15 + 5 * j + k)] = aa.dX[j][k]; h[NL * (15 + 5 * AA_M + 5 * j + k)] = aa.dF[j][k]; }
+            }
+          }
+        }
+      };
+      auto aa_fetch = [&]() {     // LDS -> registers (every lane reads its clamped leg-stage's slots)
+        if constexpr (AA_LDS) {
+          const float* h = s.aah + L;
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            aa_xb[k] = (TM)h[NL * k]; aa_fp[k] = (TM)h[NL * (5 + k)]; aa.rp[k] = h[NL * (10 + k)];
+#pragma unroll
+            for (int j = 0; j < AA_M; ++j) { aa.dX[j][k] = h[NL * (15 + 5 * j + k)]; aa.dF[j][k] = h[NL * (15 + 5 * AA_M + 5 * j + k)]; }
+          }
+        }
+      };
+      static_assert(15 + 10 * AA_M <= 45, "slots of the parked history");
       for (;;) {   // segments of iterations with the same matrix; the early rho check sits between the first two
         const int n_it = __builtin_amdgcn_readfirstlane(seg_end - it);
         bool aa_have = false;
@@ -979,6 +1006,7 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
           w_aa_reset(aa);
 #pragma unroll
           for (int k = 0; k < 5; ++k) { aa_xb[k] = A.z[k] + A.yh[k]; aa_fp[k] = aa_xb[k]; }
+          aa_park();
         }
         for (int i = 0; i < n_it; ++i) {
           // rhs = sigma u - g + rho G'(z - yh)
@@ -1030,7 +1058,9 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
               TM fx[5];
 #pragma unroll
               for (int k = 0; k < 5; ++k) fx[k] = A.z[k] + A.yh[k];
+              aa_fetch();
               w_aa_step<TM, NW>(aa, aa_xb, aa_fp, fx, aa_have, leg, s.aared, tid);
+              aa_park();
 #pragma unroll
               for (int k = 0; k < 5; ++k) {
                 const TM lo = k == 0 ? A.lo0 : ((k & 1) ? A.loA : (TM)0), hi = k == 0 ? A.hi0 : ((k & 1) ? (TM)0 : A.hiB);
