@@ -31,9 +31,9 @@ import mpcqp  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3     # MI355X fp32 vector = fp32 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0        # HBM3E spec (6290 measured float4 copy)
-TRAFFIC_FILE = "r03_hbm_traffic.json"     # PMC passes of the current kernel (profiles/), FETCH_SIZE corrected by the round-3 calibration
-SQ_FILE = "r03_pmc.txt"                     # SQ counter passes of the same kernel and workload (tools/pmc_run.sh)
-FLOPS_FILE = "r03_flops.json"               # floating-point instruction mix of the same kernel and workload (tools/pmc_flops.sh)
+TRAFFIC_FILE = "r03f_hbm_traffic.json"     # PMC passes of the current kernel (profiles/), FETCH_SIZE corrected by the round-3 calibration
+SQ_FILE = "r03f_pmc.txt"                     # SQ counter passes of the same kernel and workload (tools/pmc_run.sh)
+FLOPS_FILE = "r03f_flops.json"               # floating-point instruction mix of the same kernel and workload (tools/pmc_flops.sh)
 PEAK_VALU_ISSUE = 1024 * 2.4e9 / 4          # wave-instructions/s: 1024 SIMDs, one wave64 vector instruction per 4 cycles (an fp64 FMA: 8)
 
 

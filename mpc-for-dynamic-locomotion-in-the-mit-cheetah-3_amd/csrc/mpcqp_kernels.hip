@@ -329,7 +329,7 @@ hipError_t launch_wrench(mpcqp_engine* e, int64_t B, const FastIn<TIO>& in, void
     }
   }
   const WrTabs tabs = {e->wr_K, e->wr_kinv32, e->wr_kinv64};
-#ifndef MPCQP_DIAG_LDSPAD   // (diagnostic builds only: dynamic LDS that limits the resident workgroups per CU, tools/occupancy_study.sh)
+#ifndef MPCQP_DIAG_LDSPAD   // (diagnostic builds only: dynamic LDS that limits the resident workgroups per CU, profiles/r03f_occupancy_study.txt)
 #define MPCQP_DIAG_LDSPAD 0
 #endif
   if (e->cfg.precision == MPCQP_PREC_MIXED)

@@ -55,9 +55,10 @@ def test_host_layer_scales_the_admm_block_with_the_horizon(oracle_lib):
         assert lib.default_config(N=20, max_iter=1000).max_iter == 1000
     p10 = mpcqp.product_library().default_config()
     assert (p10.check_every, p10.max_iter) == (100, 400)
-    # other horizons run on the stage-wise engine: blocks of 2 N iterations, the polish budget of N = 20
+    # other horizons run on the stage-wise engine: blocks of 5 N / 3 iterations (its first block is Anderson-accelerated), the polish budget of N = 20
     p60 = mpcqp.product_library().default_config(N=60, delta=0.01)
-    assert (p60.check_every, p60.max_iter, p60.polish_max) == (120, 2400, 8)
+    assert (p60.check_every, p60.max_iter, p60.polish_max) == (100, 2400, 8)
+    assert p60.accel == 0 and mpcqp.product_library().default_config(accel=-1).accel == -1     # (0 = the engine's default: on)
     flags = mpcqp.product_library().default_config(
         flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_WARM_START | mpcqp.FLAG_WARM_SHIFT | mpcqp.FLAG_NATURAL_ORDER).flags
     assert flags == 1 | 2 | 16 | 8

@@ -7,7 +7,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import mpcqp
 from mpcqp import _capi
-lib = _capi.Library(os.path.join(REPO, "mpc-for-dynamic-locomotion-in-the-mit-cheetah-3_amd", "csrc", "libmpcqp_timeline.so"))
+lib = _capi.Library(os.path.join(REPO, "mpc-for-dynamic-locomotion-in-the-mit-cheetah-3_amd", "csrc", os.environ.get("TL_LIB", "libmpcqp_timeline.so")))
 _capi._product = lib
 lib.lib.mpcqp_debug_read_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 allg = ("trot", "pronk", "amble", "gallop")
