@@ -122,7 +122,8 @@ typedef struct MpcQpConfig {
   int32_t incr_legs;    /* changed leg-stages up to which a polish step updates S^-1 instead of rebuilding it; 0: 8; -1: always rebuild */
   int32_t listed_max;   /* device-fills up to which an ordered launch is one workgroup per QP (beyond: resident workgroups on a queue);
                            0: 4; -1: always queued */
-  float adapt_thr;      /* residual ratio at the early rho check beyond which a QP gets a larger penalty and a longer block; 0: per precision */
+  float adapt_thr;      /* residual ratio at the early rho check (iteration 25 of a cold solve's first block) beyond which a QP gets a larger
+                           penalty and a longer block; 0: per precision -- and NO early check where `accel` runs (horizon 10 MIXED, stage-wise engine) */
   double alpha_floor;   /* where the regulariser continuation of an alpha = 0 request ends; 0: 3e-6 (stage-wise engine: 2e-5) */
   int32_t polish_patience; /* polish steps of a round that may fail to halve the KKT violation before the round gives up; 0: default */
   int32_t polish_cheap_steps; /* ... and the further steps a round may take beyond that as long as each only UPDATES S^-1 on at most
@@ -138,6 +139,9 @@ typedef struct MpcQpConfig {
                            -1: off.  Periods that do not divide the early rho check's iteration (25) distort that check: use 5.  Changes
                            the path to the optimum (fewer iterations on slowly converging QPs), not the optimum.  MIXED arithmetic in
                            the dense engine (all-fp64 iterations run without it); a cold solve's first block in the stage-wise engine */
+  int32_t accel_restart; /* ... whose history starts afresh every `accel_restart` iterations; 0: never inside a block (the default: periods of
+                            15 / 25 / 35 / 50 iterations measured, none better than the sliding window) */
+  int32_t reserved0;
 } MpcQpConfig;
 
 typedef struct mpcqp_engine* mpcqp_handle;

@@ -46,7 +46,7 @@ class MpcQpConfig(ctypes.Structure):
         ("relax", c_double), ("max_iter", c_int32), ("check_every", c_int32),
         ("eps_abs", c_double), ("eps_rel", c_double), ("polish_max", c_int32), ("device", c_int32),
         ("first_block", c_int32), ("incr_legs", c_int32), ("listed_max", c_int32), ("adapt_thr", c_float), ("alpha_floor", c_double),
-        ("polish_patience", c_int32), ("polish_cheap_steps", c_int32), ("polish_cheap_legs", c_int32), ("hard_block_x10", c_int32), ("polish_last_patience", c_int32), ("accel", c_int32),
+        ("polish_patience", c_int32), ("polish_cheap_steps", c_int32), ("polish_cheap_legs", c_int32), ("hard_block_x10", c_int32), ("polish_last_patience", c_int32), ("accel", c_int32), ("accel_restart", c_int32), ("reserved0", c_int32),
     ]
 
     def as_dict(self):

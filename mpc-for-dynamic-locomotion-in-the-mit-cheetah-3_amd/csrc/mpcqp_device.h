@@ -55,6 +55,8 @@ struct DevCfg {
   int last_patience;    // wrench engine: patience of a round that nothing follows (0: unlimited)
   int refine_admm;      // all-fp64 ADMM without polish at tolerances below 1e-6: one refinement step per linear solve
   int accel_p;          // Anderson acceleration of the ADMM blocks: an extrapolation every accel_p iterations (0: off)
+  int early_check;      // the single early rho check of a cold solve's first block (off by default where the acceleration runs)
+  int accel_restart;    // iterations after which the acceleration's history starts afresh (0: only with a new matrix)
 };
 
 // Sum over the 8 lanes of a leg group with DPP lane moves (no LDS crossbar): quad butterfly, then half-row mirror.

@@ -578,6 +578,14 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   d.accel_p = !(cfg->flags & MPCQP_FLAG_POLISH) ? 0 : (cfg->accel > 0 ? cfg->accel : (cfg->accel < 0 ? 0 : 5));
   const bool accel_dense = d.accel_p > 0 && cfg->precision != MPCQP_PREC_F64 && (N == 10 || N == 20) && !(cfg->flags & MPCQP_FLAG_STAGE_KERNEL);
   const bool accel_n10 = accel_dense && N == 10;   // (the block lengths below were swept with the acceleration on the dense engine only)
+  // The early rho check (iteration 25) was built for the plain iteration: it buys a slowly converging QP a larger penalty and a
+  // longer block up front.  With the acceleration it costs more than it brings -- the residual ratio it reads is taken a few iterations
+  // after an extrapolation, the rebuild restarts the history, and the extrapolation does for those QPs what the penalty did.  Never
+  // flagging: horizon 10 held-out mean 9.9 -> 10.7 M QP/s, B = 65 536 15.6 -> 16.4 M; stage-wise engine at N = 60: the 1000 logged
+  // ticks 143 -> 221 k QP/s (MIXED: every tick solved in its first block), synthetic 62 -> 93 k (profiles/r03f_early_check.txt).
+  // Horizon 20 (config 5): 1.32 -> 1.65 M.  So where the acceleration runs the check is off unless the caller asks for it with an explicit adapt_thr.
+  d.early_check = (cfg->adapt_thr > 0 || !accel_dense) ? 1 : 0;   // (stage-wise engine: decided below, once the engine is known)
+  d.accel_restart = (d.accel_p > 0 && cfg->accel_restart > 0) ? cfg->accel_restart : 0;
   // A cold solve's first ADMM block is 0.7 check_every long: most QPs have their active set by then (mean iterations 114 -> 82 at
   // N = 10, B = 65 536: 14.6 -> 16.2 M QP/s, N = 20: +10 %), the others go on in full blocks; at B = 4096, where the launch is as
   // long as its hardest QPs, neutral (eight batches of other seeds, tools/adapt_sweep.py).  With the polish only: an ADMM-only
@@ -627,6 +635,8 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
     // alpha = 0 optimum on the golden log ticks at N = 10 / 20 / 60; at 1e-5 the polish refinement stops contracting at N = 60,
     // tools/stage_floor.py)
     if (!(cfg->alpha_floor > 0)) e->dev.alpha_floor = SG_ALPHA_FLOOR;
+    if (!(cfg->adapt_thr > 0) && e->dev.accel_p > 0) e->dev.early_check = 0;   // (accelerated first block: no early rho check, see above)
+    else e->dev.early_check = 1;
     int per_cu = 0;
     const bool f64 = e->cfg.precision == MPCQP_PREC_F64;
     hipError_t oe;

@@ -841,7 +841,10 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
   float rho = s.rho;
   int K = kfirst > 0 ? min(kfirst, cfg.check_every) : cfg.check_every;
   K = max(1, min(K, cfg.max_iter - s.iters));
-  int it = 0, seg_end = (adapt && MPCQP_W_ADAPT_AT < K) ? MPCQP_W_ADAPT_AT : K;
+  const int seg_len = (aa_on && cfg.accel_p > 0 && cfg.accel_restart > 0) ? cfg.accel_restart : (1 << 30);   // (segments: see w_admm)
+  const bool check = adapt && cfg.early_check;
+  // (a cold solve's first block is split at ADAPT_AT with or without the check: the history's one fresh start there is worth 2-3 %)
+  int it = 0, seg_end = min(K, (adapt && MPCQP_W_ADAPT_AT < K) ? MPCQP_W_ADAPT_AT : seg_len);
   int hard = 0;
   float ratio = 0.f;
   STAMP_INIT
@@ -928,15 +931,15 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
       }
       STAMP(2);
       if (it >= K) break;
-      {
+      if (check && !hard && it == MPCQP_W_ADAPT_AT) {
         double y5[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) y5[k] = r * yh[k];
         ratio = sg_ratio(s, Lg, u, z, y5, N, tid);
+        STAMP(3);
+        if (ratio > cfg.adapt_thr) { rebuild = true; break; }   // uniform
       }
-      STAMP(3);
-      if (ratio > cfg.adapt_thr) { rebuild = true; break; }   // uniform
-      seg_end = K;
+      seg_end = min(K, it + seg_len);
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) { Lg.ua[a] = u[a]; Lg.pu[a] = u[a]; }
@@ -946,7 +949,7 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
     rho = fminf(rho * ratio, ADAPT_RHO_MAX);
     hard = 1;
     K = max(K, min((cfg.hard_x10 * K) / 10, cfg.max_iter - s.iters));
-    seg_end = K;
+    seg_end = min(K, it + seg_len);
   }
   __syncthreads();
   if (tid == 0) { s.rho = rho; s.iters += K; s.hard |= hard; }

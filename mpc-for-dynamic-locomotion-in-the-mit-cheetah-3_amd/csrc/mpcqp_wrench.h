@@ -918,7 +918,12 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
   float rho = s.rho;
   int K = kfirst > 0 ? min(kfirst, cfg.check_every) : cfg.check_every;
   K = max(1, min(K, cfg.max_iter - __builtin_amdgcn_readfirstlane(s.iters)));   // (the iteration cap is exact)
-  int it = 0, seg_end = (adapt && MPCQP_W_ADAPT_AT < K) ? MPCQP_W_ADAPT_AT : K;
+  // Segments of iterations: the early rho check (if any) sits after the first ADAPT_AT iterations, and the acceleration's history starts
+  // afresh with every segment -- every cfg.accel_restart iterations where it runs
+  const int seg_len = (!REFINE && sizeof(TM) == 4 && cfg.accel_p > 0 && cfg.accel_restart > 0) ? cfg.accel_restart : (1 << 30);
+  const bool check = adapt && cfg.early_check;
+  // (a cold solve's first block is split at ADAPT_AT with or without the check: the history's one fresh start there is worth 2-3 %)
+  int it = 0, seg_end = min(K, (adapt && MPCQP_W_ADAPT_AT < K) ? MPCQP_W_ADAPT_AT : seg_len);
   int hard = 0;
   float ratio = 0.f;
   STAMP_INIT
@@ -1074,16 +1079,16 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
         it = seg_end;
         STAMP(4);
         if (it >= K) break;
-        {   // the single early rho check: OSQP's residual ratio after the first ADAPT_AT iterations
+        if (check && !hard && it == MPCQP_W_ADAPT_AT) {   // the single early rho check: OSQP's residual ratio after the first ADAPT_AT iterations
           const TV u3[3] = {(TV)A.u[0], (TV)A.u[1], (TV)A.u[2]}, g3[3] = {(TV)A.g[0], (TV)A.g[1], (TV)A.g[2]};
           TV z5[5], y5[5];
 #pragma unroll
           for (int k = 0; k < 5; ++k) { z5[k] = (TV)A.z[k]; y5[k] = (TV)rho * (TV)A.yh[k]; }
           ratio = w_ratio<TV, N>(s, tabs, u3, z5, y5, g3, (TV)A.mu, leg, tid);
+          STAMP(5);
+          if (ratio > cfg.adapt_thr) { rebuild = true; break; }      // uniform: slowly converging QP -> larger penalty, rebuilt matrix
         }
-        STAMP(5);
-        if (ratio > cfg.adapt_thr) { rebuild = true; break; }        // uniform: slowly converging QP -> larger penalty, rebuilt matrix
-        seg_end = K;
+        seg_end = min(K, it + seg_len);
       }
       if (leg) {
 #pragma unroll
@@ -1097,7 +1102,7 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
     rho = fminf(rho * ratio, ADAPT_RHO_MAX);   // ... and a longer block
     hard = 1;
     K = max(K, min((cfg.hard_x10 * K) / 10, cfg.max_iter - __builtin_amdgcn_readfirstlane(s.iters)));
-    seg_end = K;
+    seg_end = min(K, it + seg_len);
   }
   if (fresh_tid<NW>(tid0) == 0) { s.rho = rho; s.iters += K; s.hard |= hard; }
   wsync<NW>();

@@ -10,10 +10,13 @@ combos = [(-1, 200, 0, 0), (5, 200, 0, 0), (5, 200, 120, 0), (5, 200, 100, 0), (
 if len(sys.argv) > 1:
     combos = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
 ref = {}
-for ac, ce, fb, hx in combos:
-    line = f"accel {ac:2d} check_every {ce} first_block {fb:3d} hard_x10 {hx:2d}:"
+for combo in combos:
+    ac, ce, fb, hx = combo[:4]
+    extra = {'adapt_thr': float(combo[4])} if len(combo) > 4 and combo[4] > 0 else {}
+    if os.environ.get('AS_RESTART'): extra['accel_restart'] = int(os.environ['AS_RESTART'])
+    line = f"accel {ac:2d} check_every {ce} first_block {fb:3d} hard_x10 {hx:2d} {extra}:"
     for name, b in batches.items():
-        sol = mpcqp.MPCBatch(N=20, precision="mixed", accel=ac, check_every=ce, first_block=fb, hard_block_x10=hx, max_iter=800, flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)
+        sol = mpcqp.MPCBatch(N=20, precision="mixed", accel=ac, check_every=ce, first_block=fb, hard_block_x10=hx, max_iter=800, flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING, **extra)
         dev = sol.upload(b)
         for _ in range(2):
             out = sol.solve_batch(dev["x0"], dev["r"], dev["contact"], dev["xdes"], dev["mu"])

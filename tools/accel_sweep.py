@@ -18,9 +18,13 @@ combos = [(-1, 0, 0, 100), (5, 0, 0, 100), (4, 0, 0, 100), (6, 0, 0, 100), (8, 0
 if len(sys.argv) > 1:
     combos = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
 ref_u = {}
-for ac, fb, hx, ce in combos:
-    sol = mpcqp.MPCBatch(N=10, precision="mixed", accel=ac, first_block=fb, hard_block_x10=hx, check_every=ce, flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING)
-    line = f"accel {ac:2d} first_block {fb:3d} hard_x10 {hx:2d} check_every {ce:3d}:"
+for combo in combos:
+    ac, fb, hx, ce = combo[:4]
+    extra = {}
+    if os.environ.get('AS_RESTART'): extra['accel_restart'] = int(os.environ['AS_RESTART'])
+    if len(combo) > 4 and combo[4] > 0: extra['adapt_thr'] = float(combo[4])
+    sol = mpcqp.MPCBatch(N=10, precision="mixed", accel=ac, first_block=fb, hard_block_x10=hx, check_every=ce, flags=mpcqp.FLAG_POLISH | mpcqp.FLAG_NO_TIMING, **extra)
+    line = f"accel {ac:2d} first_block {fb:3d} hard_x10 {hx:2d} check_every {ce:3d}" + (f" {extra}" if extra else "") + ":"
     rates = []
     for sd in seeds:
         dev = sol.upload(batches[sd])

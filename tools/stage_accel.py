@@ -13,11 +13,16 @@ ref = {}
 combos = [(-1, 120, 0), (5, 120, 0), (5, 100, 0), (5, 80, 0), (5, 120, 60), (5, 100, 50), (8, 120, 0), (3, 120, 0)]
 if len(sys.argv) > 1:
     combos = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
-for ac, ce, fb in combos:
-    line = f"accel {ac:2d} check_every {ce} first_block {fb}:"
+for combo in combos:
+    ac, ce, fb = combo[:3]
+    extra = {}
+    if os.environ.get('AS_RESTART'): extra['accel_restart'] = int(os.environ['AS_RESTART'])
+    if len(combo) > 3 and combo[3] > 0: extra['adapt_thr'] = float(combo[3])
+    if len(combo) > 4 and combo[4] > 0: extra['hard_block_x10'] = int(combo[4])
+    line = f"accel {ac:2d} check_every {ce} first_block {fb} {extra}:"
     for prec in ("mixed", "f64"):
         for name, b in (("logged", logged), ("synthetic", synth)):
-            o = gpu_solve(b, 60, 0.01, prec, alpha=1e-2, check_every=ce, max_iter=2400, polish_max=8, accel=ac, first_block=fb)
+            o = gpu_solve(b, 60, 0.01, prec, alpha=1e-2, check_every=ce, max_iter=2400, polish_max=8, accel=ac, first_block=fb, **extra)
             it = o["iters"] % 1000; ps = o["iters"] // 1000
             u = o["u"].reshape(len(it), -1)
             key = (prec, name)
