@@ -250,6 +250,20 @@ def test_anderson_acceleration_changes_the_path_not_the_optimum(oracle_solve):
     assert not np.array_equal(s_on["iters"], s_off["iters"])
 
 
+def test_early_rho_check_and_history_restarts_are_switches_not_results(oracle_solve):
+    """Where the iterations are accelerated the early rho check is off by default; an explicit `adapt_thr` brings it back, and
+    `accel_restart` restarts the extrapolation's history periodically.  Both change iteration counts, neither changes an optimum."""
+    b = mpcqp.synth.config3(512)
+    ref = oracle_solve(b)
+    base = gpu_solve(b, io="f64", precision="mixed")
+    for kw in ({"adapt_thr": 6.0}, {"accel_restart": 25}):
+        o = gpu_solve(b, io="f64", precision="mixed", **kw)
+        ok = solved(o["status"])
+        assert ok.mean() >= 0.998
+        assert rel_err(o["u"], ref["u"])[ok].max() <= 1e-4
+        assert not np.array_equal(o["iters"], base["iters"]), kw
+
+
 def test_anderson_acceleration_leaves_admm_only_runs_alone():
     """Without MPCQP_FLAG_POLISH the engine is OSQP's algorithm 1 (what the reference runs, src/mpc.py:51-55), whatever `accel` says:
     same bits with the field at its default, at 5 and at -1."""
