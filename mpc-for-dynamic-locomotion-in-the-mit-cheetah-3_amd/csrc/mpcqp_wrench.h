@@ -341,6 +341,129 @@ __device__ __forceinline__ void w_sweep(WTile<TM>& t, TM* __restrict__ piv, int 
   }
 }
 
+#ifdef MPCQP_SYM_SWEEP
+// ----------------------------------------------------------------------------------------------------- symmetric sweep (polish, horizon 10)
+// EXPERIMENT, compiled only with -DMPCQP_SYM_SWEEP (round 3: correct -- all GPU tests green -- and no faster: profiles/r03f_symmetric_sweep.txt).
+// S = K^-1 + E is symmetric, and so is every intermediate of the symmetric sweep: sweep only the lower block triangle.  In the
+// stage-major ordering the 60 x 60 matrix is a 10 x 10 grid of 6 x 6 stage blocks; lane l = bi (bi + 1) / 2 + bj holds block (bi, bj),
+// bi >= bj -- 55 lanes, 36 values each instead of 64: 36 instead of 64 fp64 FMAs per pivot and lane.  K^-1 = (+)_q K_q^-1 puts ONE entry
+// on each diagonal position of a block and E_j is the diagonal block (j, j) itself, so the initialisation is six table loads per lane.
+// A pivot row k = 6 p + r is published by the lanes of block row p (their local row r) and, for the columns right of the diagonal, by
+// the lanes of block column p (their local COLUMN r: S[k][c] = S[c][k]).  Afterwards the inverse is handed to the 8 x 8 lane grid of
+// 8 x 8 tiles that the solves and the rank-one updates work on, block row by block row through the 360 doubles of s.E -- and that
+// hand-over (~4 k cycles) takes back what the sweep saves (95 instructions per pivot with 38 fp64 FMAs against 101 with 64).  What
+// would make it pay: solves and updates on the symmetric layout too.
+struct WSym { double v[6][6]; };
+
+__device__ __forceinline__ void sympin(WSym& t) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a) asm volatile("" : "+v"(t.v[a][0]), "+v"(t.v[a][1]), "+v"(t.v[a][2]), "+v"(t.v[a][3]), "+v"(t.v[a][4]), "+v"(t.v[a][5]));
+}
+__device__ __forceinline__ void ld6(const double* p, double (&o)[6]) {
+#pragma unroll
+  for (int h = 0; h < 3; ++h) { const double2 a = reinterpret_cast<const double2*>(p)[h]; o[2 * h] = a.x; o[2 * h + 1] = a.y; }
+}
+__device__ __forceinline__ void st6(double* p, const double (&o)[6]) {
+#pragma unroll
+  for (int h = 0; h < 3; ++h) reinterpret_cast<double2*>(p)[h] = make_double2(o[2 * h], o[2 * h + 1]);
+}
+
+// tile <- -(K^-1 + E)^-1 in the 8 x 8 grid layout, by way of the symmetric half.  kq: [6][10][10] K_q^-1; E: the ten 6 x 6 blocks of
+// T D^-1 T' (consumed by the initialisation, then reused as the hand-over buffer); piv: pivot-row broadcast.
+__device__ __forceinline__ void w_sym_build(WTile<double>& tile, const double* __restrict__ kq, double* __restrict__ E, double* __restrict__ piv,
+                                            int tid) {
+  constexpr int N = 10;
+  asm volatile("" : "+v"(tid));
+  const int l = min(tid, 54);
+  const int bi = (l >= 1) + (l >= 3) + (l >= 6) + (l >= 10) + (l >= 15) + (l >= 21) + (l >= 28) + (l >= 36) + (l >= 45);
+  const int bj = l - ((bi * (bi + 1)) >> 1);
+  const bool on = tid < 55;
+  WSym t;
+  {   // initialisation
+    double kd[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) kd[a] = kq[(a * N + bi) * N + bj];
+    const bool dg = bi == bj;
+    const double* Eb = E + 36 * bi;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const double e = Eb[6 * a + b];
+        t.v[a][b] = (a == b ? kd[a] : 0.0) + (dg ? e : 0.0);
+      }
+    }
+  }
+  wsync<1>();   // (E has been read: its bytes serve the hand-over below; nothing else writes them during the sweep)
+  for (int p = 0; p < N; ++p) {
+    const bool prow = bi == p, pcol = bj == p;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      {   // publish pivot row k = 6 p + r
+        double o[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) o[c] = prow ? t.v[r][c] : t.v[c][r];   // block row p: local row r;  block column p below the diagonal: local column r
+        if (on && (prow || pcol)) st6(piv + 6 * (prow ? bj : bi), o);
+      }
+      wsync<1>();
+      const double pinv = w_rcp(piv[6 * p + r]);
+      double vr[6], vc[6], m[6];
+      ld6(piv + 6 * bi, vr);
+      ld6(piv + 6 * bj, vc);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { vr[a] *= pinv; m[a] = vr[a]; }
+      m[r] = prow ? 1.0 - pinv : vr[r];     // (the owner's pivot row comes out of the same FMAs: its tile row IS the published row)
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const double ma = -m[a];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) t.v[a][b] = fma(ma, vc[b], t.v[a][b]);
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {         // pivot column (selects, as in w_sweep)
+        const double v = (a == r && prow) ? -pinv : vr[a];
+        t.v[a][r] = pcol ? v : t.v[a][r];
+      }
+      wsync<1>();
+      sympin(t);
+    }
+  }
+  // hand-over to the 8 x 8 grid: block row p of the full matrix (6 rows x 60 columns) through E
+  const int gr = tid >> 3, gc = tid & 7;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile.v[i][j] = (8 * gr + i >= 60 && i == j && gr == gc) ? 1.0 : 0.0;   // identity on the padding
+  }
+  for (int p = 0; p < N; ++p) {
+    if (on && bi == p) {                    // rows 6 p .. 6 p + 5, columns of block bj
+#pragma unroll
+      for (int a = 0; a < 6; ++a) st6(E + 60 * a + 6 * bj, t.v[a]);
+    } else if (on && bj == p) {             // the same rows, columns of block bi > p: the transposed block
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        double o[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) o[a] = t.v[a][b];
+        st6(E + 60 * b + 6 * bi, o);
+      }
+    }
+    wsync<1>();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int a = 8 * gr + i - 6 * p;     // local row of this block row, if any
+      if ((unsigned)a < 6u) {
+        double o[8];
+        ld8<double>(E + 60 * a + 8 * gc, o);     // (gc = 7 reads four doubles into the next row / the bytes after E: masked below)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile.v[i][j] = (8 * gc + j < 60) ? o[j] : 0.0;
+      }
+    }
+    wsync<1>();
+  }
+}
+#endif
+
 // y = S^-1 x for x in LDS (bv, padded layout): returns element 8 gr + gc (valid on lanes gc < 8) and writes it to cv.
 template <typename TM, int N>
 __device__ __forceinline__ void w_matvec(const WTile<TM>& t, const TM* __restrict__ bv, TM* __restrict__ cv, int gr, int gc) {
@@ -1236,9 +1359,17 @@ __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tab
     WTile<TP> tile;
     {   // ---- S = K^-1 + E, swept in place
       const int tid = fresh_tid<NW>(tid0), gr = tid / G, gc = tid % G;
-      w_tile_init<TP, N>(tile, kinvT, E, gr, gc, tid);
-      STAMP(10);
-      w_sweep<TP, N>(tile, piv, gr, gc);
+#ifdef MPCQP_SYM_SWEEP   // (experiment: the lower block triangle only, see w_sym_build)
+      if constexpr (N == 10 && NW == 1 && sizeof(TP) == 8) {
+        w_sym_build(tile, kinvT, E, piv, tid);
+        STAMP(10);
+      } else
+#endif
+      {
+        w_tile_init<TP, N>(tile, kinvT, E, gr, gc, tid);
+        STAMP(10);
+        w_sweep<TP, N>(tile, piv, gr, gc);
+      }
     }
     STAMP(11);
     int in_row = 0;
