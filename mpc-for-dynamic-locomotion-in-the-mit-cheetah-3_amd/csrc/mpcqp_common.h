@@ -45,6 +45,12 @@ constexpr int WARM_POLISH = MPCQP_WARM_POLISH;   // polish steps tried on a warm
 #define MPCQP_WARM_K 60
 #endif
 constexpr int WARM_K = MPCQP_WARM_K;             // length of the first ADMM block when it starts from remembered (u, y)
+#ifndef MPCQP_WARM_FRAC10
+#define MPCQP_WARM_FRAC10 4
+#endif
+constexpr int WARM_FRAC10 = MPCQP_WARM_FRAC10;   // ... in tenths of a cold solve's first block (at most WARM_K): 24 iterations at horizon 10
+                                                 // (roll-out of 4096 robots x 100 ticks: 2 / 3 / 4 / 6 / 8 / 10 tenths -> 12.9 / 13.5 / 15.0 / 14.3 / 14.0 / 13.4 M
+                                                 //  robot-ticks/s, cold solves 13.4 M; profiles/r03f_rollout_warm.txt)
 constexpr float WARM_KKT_TOL = 1e-3f;            // (u0, y0) counts as a KKT point when its stationarity residual is below this x |g|
 
 // ------------------------------------------------------------------------------------------------------ dispatch order

@@ -914,7 +914,7 @@ __device__ __forceinline__ void sg_admm(SmemS& s, const DevCfg& cfg, SLeg& Lg, d
         }
         if (aa_p > 0 && --aa_left == 0) {   // uniform
           aa_left = aa_p;
-          if (it + 1 < seg_end) {           // (the block's last iterate is a genuine ADMM iterate: the polish starts from it)
+          if (it + 1 + aa_p <= seg_end) {   // (the segment ends with at least a period of genuine ADMM iterations, see w_admm)
             double fx[5];
 #pragma unroll
             for (int k = 0; k < 5; ++k) fx[k] = z[k] + yh[k];

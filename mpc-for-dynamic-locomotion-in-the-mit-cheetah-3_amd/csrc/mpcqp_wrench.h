@@ -1182,7 +1182,9 @@ __device__ __forceinline__ void w_admm(SmemW<TV, N>& s, const DevCfg& cfg, const
           }
           if (aa_p > 0 && --aa_left == 0) {   // uniform
             aa_left = aa_p;
-            if (i + 1 < n_it) {               // (the block's last iterate is a genuine ADMM iterate: the polish starts from it)
+            if (i + 1 + aa_p <= n_it) {       // (the segment ends with at least a period of genuine ADMM iterations: the polish -- or the
+                                              //  next history -- starts from a settled iterate; one plain iteration after an extrapolation is not one:
+                                              //  warm-started blocks of 36 = 25 + 11 iterations were slower than blocks of 24, profiles/r03f_rollout_warm.txt)
               TM fx[5];
 #pragma unroll
               for (int k = 0; k < 5; ++k) fx[k] = A.z[k] + A.yh[k];
@@ -1763,7 +1765,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       int budget = kind == R_WARM ? min(warm_tries, polish_max) : 2 * polish_max;
       const bool admm_only = !(cfg.flags & MPCQP_FLAG_POLISH);
       if (kind == R_ADMM) {
-        w_admm<TV, TM, N, REFINE>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, round == 0 ? (warm >= 2 ? (cfg.first_block > 0 ? min(WARM_K, (6 * cfg.first_block) / 10) : WARM_K) : cfg.first_block) : 0, tid0);
+        w_admm<TV, TM, N, REFINE>(s, cfg, tabs, kinvM, round == 0 ? 1 : 0, round == 0 ? (warm >= 2 ? (cfg.first_block > 0 ? min(WARM_K, (WARM_FRAC10 * cfg.first_block) / 10) : WARM_K) : cfg.first_block) : 0, tid0);
         budget = admm_only ? 0 : (__builtin_amdgcn_readfirstlane(s.hard) ? HARD_POLISH_FACTOR : 1) * polish_max;
       }
       // Active-set steps while they make progress: a step that does not at least halve the KKT violation of the previous one

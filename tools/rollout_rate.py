@@ -6,6 +6,9 @@ import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import mpcqp
+if os.environ.get("AS_LIB"):   # a variant build of the library
+    from mpcqp import _capi
+    _capi._product = _capi.Library(os.path.join(REPO, "mpc-for-dynamic-locomotion-in-the-mit-cheetah-3_amd", "csrc", os.environ["AS_LIB"]))
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 100
