@@ -34,6 +34,12 @@ constexpr int SG_NS = 64;                 // stages a workgroup can hold
 constexpr int SG_NT = 256, SG_NW = 4;     // one lane per leg-stage
 constexpr int SG_NQ = 6 * SG_NS;
 constexpr int SG_TL_MIN = 24;             // horizons from which the two recursions of a solve run two-level (eight chunks in parallel)
+#ifndef MPCQP_SG_WARM_FRAC10
+#define MPCQP_SG_WARM_FRAC10 4
+#endif
+constexpr int SG_WARM_FRAC10 = MPCQP_SG_WARM_FRAC10;   // first block of a solve warm-started from a neighbour, in tenths of a cold solve's
+                                                       // (one robot on consecutive logged ticks: 3 / 4 / 6 / 8 tenths -> 1134 / 1122 / 1039 / 1017 solves/s, cold 855;
+                                                       //  profiles/r03f_stage_warm.txt)
 constexpr double SG_ALPHA_FLOOR = 2e-5;   // where this engine's continuation of an alpha = 0 request ends (mpcqp_kernels.hip)
 // Workspace of one resident workgroup, in doubles: the fp64 chains' factor matrices, per stage  Lrow (128) | Lcol (128)  (the fp32
 // chains keep theirs in LDS for the whole ADMM block).
@@ -1199,7 +1205,7 @@ mpcqp_stage_solve(const DevCfg* __restrict__ cfgp, const FastIn<TIO> in, TIO* ug
       int budget = kind == R_WARM ? min(warm_tries, polish_max) : 2 * polish_max;
       if (kind == R_ADMM) {
         // (a warm start from remembered (u, y): a first block 0.6 of the cold one, as in the dense engine)
-        sg_admm<TM>(s, cfg, Lg, ws, round == 0 ? 1 : 0, round == 0 ? (warm >= 2 ? max(1, (6 * (cfg.first_block > 0 ? cfg.first_block : cfg.check_every)) / 10) : cfg.first_block) : 0, N, tid,
+        sg_admm<TM>(s, cfg, Lg, ws, round == 0 ? 1 : 0, round == 0 ? (warm >= 2 ? max(1, (SG_WARM_FRAC10 * (cfg.first_block > 0 ? cfg.first_block : cfg.check_every)) / 10) : cfg.first_block) : 0, N, tid,
                     round == 0);   // (the acceleration: in the first block only, see sg_admm)
         budget = admm_only ? 0 : (s.hard ? HARD_POLISH_FACTOR : 1) * polish_max;
       }
