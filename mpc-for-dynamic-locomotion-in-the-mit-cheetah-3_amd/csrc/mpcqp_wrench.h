@@ -944,6 +944,12 @@ __device__ __forceinline__ void w_aa_step(LegAA& h, TM (&xb)[5], TM (&fp)[5], co
   static_assert(AA_M == 3 || AA_M == 2, "the solve below is written for two or three columns");
   constexpr int M = AA_M, NQ_ = M * (M + 1) / 2 + M;
   float r[5];
+  if (!have_prev) {   // (uniform) the first image of a history: nothing to combine yet -- file it and go on from it
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { h.rp[k] = leg ? (float)(fx[k] - xb[k]) : 0.f; fp[k] = fx[k]; xb[k] = fx[k]; }
+    have_prev = true;
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     r[k] = leg ? (float)(fx[k] - xb[k]) : 0.f;
