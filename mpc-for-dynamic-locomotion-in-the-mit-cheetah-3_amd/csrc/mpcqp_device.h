@@ -45,6 +45,7 @@ struct DevCfg {
   int max_iter, check_every, polish_max;
   unsigned flags;
   double alpha_floor;   // wrench engine: where the regulariser continuation of an alpha = 0 request ends
+  double alpha_target, alpha_start;   // ... the regulariser a solve ends with (alpha, or alpha_floor for a request of 0) and the one it starts with (>= 1e-2 with the polish)
   int first_block;      // wrench engine: iterations of a cold solve's first ADMM block (0: check_every)
   int incr_legs;        // wrench engine: changed leg-stages up to which a polish step updates the inverse (0: always rebuild)
   float adapt_thr;      // wrench engine: residual ratio at the early rho check beyond which a QP gets a larger penalty and a longer block

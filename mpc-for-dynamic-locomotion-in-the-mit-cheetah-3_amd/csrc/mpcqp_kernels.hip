@@ -654,6 +654,9 @@ int mpcqp_create(const MpcQpConfig* cfg, mpcqp_handle* out) {
   if (e->cfg.precision == MPCQP_PREC_F32) e->cfg.precision = MPCQP_PREC_MIXED;
   delete[] tab;
   if (he == hipSuccess) he = hipMalloc((void**)&e->dcfg, sizeof(DevCfg));
+  // the regulariser a solve ends with and the one it starts with (continuation, mpcqp_wrench.h): decided here, not per QP on the device
+  e->dev.alpha_target = e->dev.alpha > 0.0 ? e->dev.alpha : ((e->dev.flags & MPCQP_FLAG_POLISH) ? e->dev.alpha_floor : 0.0);
+  e->dev.alpha_start = ((e->dev.flags & MPCQP_FLAG_POLISH) && e->dev.alpha < ALPHA_EASY) ? ALPHA_EASY : e->dev.alpha;
   if (he == hipSuccess) he = hipMemcpy(e->dcfg, &e->dev, sizeof(DevCfg), hipMemcpyHostToDevice);
   if (he == hipSuccess) he = hipEventCreate(&e->ev0);
   if (he == hipSuccess) he = hipEventCreate(&e->ev1);

@@ -82,6 +82,18 @@ struct SmemW {
 };
 
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// A zero the optimiser cannot see through.  A 64-bit constant needs a register pair, LLVM hoists such pairs out of the persistent QP loop,
+// and with the register file full it then SPILLS the constant at kernel entry and reloads it per QP (scratch stores are written through:
+// 10 bytes per lane and wave of HBM writes for three zeros and a one, profiles/r03f_hbm_traffic.json).  Materialised where it is used instead.
+__device__ __forceinline__ double opaque_zero_f64() {
+  unsigned lo, hi;
+  asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "=v"(lo), "=v"(hi));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <typename T> __device__ __forceinline__ T opaque_zero() {
+  if constexpr (sizeof(T) == 8) return (T)opaque_zero_f64();
+  else { float z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return (T)z; }
+}
 // A wave-uniform float, moved to a scalar register (loop-carried uniform values otherwise occupy a vector register each).
 __device__ __forceinline__ float ufloat(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
 // The thread index of a register phase.  One wave per QP: recomputed from the lane counter where it is needed (two VALU
@@ -648,7 +660,7 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
       s.delta = (TV)cfg.delta; s.theta = (TV)cfg.theta; s.inv_m = (TV)cfg.inv_m;
       s.fmin = (TV)cfg.fmin; s.fmax = (TV)cfg.fmax;
     }
-    for (int i = tid; i < DP; i += NT) { s.bv[i] = 0.0; s.cv[i] = 0.0; s.piv[i] = 0.0; s.piv[DP + i] = 0.0; }   // pad slots stay finite
+    { const double z = opaque_zero_f64(); for (int i = tid; i < DP; i += NT) { s.bv[i] = z; s.cv[i] = z; s.piv[i] = z; s.piv[DP + i] = z; } }   // pad slots stay finite
   }
   int bad = w_load<TV, TIO, N>(s, in, b, tid);
   if constexpr (NW == 1) {
@@ -721,8 +733,11 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
     s.gam[e] = (TV)2 * (s.wP[q] * d * d * aP + s.wQ[q] * d * aQ);
   }
   wsync<NW>();   // the free response has been consumed: its bytes become the ADMM iterate
-  for (int i = tid; i < n; i += NT) { s.uv[i] = 0; s.ua[i] = 0; s.pu[i] = 0; }
-  for (int i = tid; i < NL * 5; i += NT) { s.za[i] = 0; s.ya[i] = 0; s.py[i] = 0; }
+  {
+    const TV z = opaque_zero<TV>();
+    for (int i = tid; i < n; i += NT) { s.uv[i] = z; s.ua[i] = z; s.pu[i] = z; }
+    for (int i = tid; i < NL * 5; i += NT) { s.za[i] = z; s.ya[i] = z; s.py[i] = z; }
+  }
   wsync<NW>();
   float q[1] = {0.f};
   if (tid < NL) {   // linear term g = T' gam (the gradient at u = 0)
@@ -738,7 +753,7 @@ __device__ __forceinline__ int w_setup(SmemW<TV, N>& s, const DevCfg& cfg, const
     }
   }
   wmax<1, NW>(q, s.red, tid);
-  if (tid == 0) { s.gmax = q[0]; s.rho = (float)cfg.rho; s.iters = 0; s.psteps = 0; s.hard = 0; s.warm = 0; }
+  if (tid == 0) { const int z = opaque(0); s.gmax = q[0]; s.rho = (float)cfg.rho; s.iters = z; s.psteps = z; s.hard = z; s.warm = z; }   // (an opaque zero: see opaque_zero_f64)
   // (s.alpha: set by the kernel before the setup -- the regulariser the solve STARTS with, see the continuation in the kernel)
   wsync<NW>();
 #if defined(MPCQP_STAMPS) || defined(MPCQP_WDBG)
@@ -783,8 +798,9 @@ __device__ __forceinline__ void w_warm_start(SmemW<TV, N>& s, const WrTabs& tabs
   wmax<2, NW>(amax, s.red, tid);
   wsync<NW>();
   if (!(amax[0] > 0.f)) {                                 // uniform: no guess
-    for (int i = tid; i < NL * 5; i += NT) s.ya[i] = 0;
-    for (int i = tid; i < n; i += NT) s.uv[i] = 0;
+    const TV z = opaque_zero<TV>();
+    for (int i = tid; i < NL * 5; i += NT) s.ya[i] = z;
+    for (int i = tid; i < n; i += NT) s.uv[i] = z;
     wsync<NW>();
     return;
   }
@@ -823,7 +839,7 @@ __device__ __forceinline__ void w_warm_start(SmemW<TV, N>& s, const WrTabs& tabs
       }
     }
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { s.py[5 * L + i] = y[i]; s.za[5 * L + i] = (TV)z[i]; if (!duals) s.ya[5 * L + i] = 0; }
+    for (int i = 0; i < 5; ++i) { s.py[5 * L + i] = y[i]; s.za[5 * L + i] = (TV)z[i]; if (!duals) s.ya[5 * L + i] = opaque_zero<TV>(); }
   }
   wmax<1, NW>(rs, s.red, tid);
   if (tid == 0) s.warm = !duals ? 1 : (rs[0] <= WARM_KKT_TOL * fmaxf(s.gmax, 1.f) ? 2 : 3);
@@ -1387,7 +1403,7 @@ __device__ __forceinline__ int w_polish_round(SmemW<TV, N>& s, const WrTabs& tab
       // ---- phase C: solve in the free variables from the projection of pu, duals, KKT
       const int tid = fresh_tid<NW>(tid0), L = min(tid, NL - 1), gr = tid / G, gc = tid % G;
       const bool leg = tid < NL, stance = s.ct[L] != 0;
-      if (tid >= WG<N>::NQ && tid < WG<N>::DP) bv[tid] = (TP)0;   // pad slots of the mat-vec input, in this phase's element type
+      if (tid >= WG<N>::NQ && tid < WG<N>::DP) bv[tid] = opaque_zero<TP>();   // pad slots of the mat-vec input, in this phase's element type
       const ActSet as(s.aset[L], stance);
       const int zs = as.zs, xs = as.xs, ys = as.ys;
       const bool ez = as.ez, ex = as.ex, ey = as.ey;
@@ -1741,8 +1757,8 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
     // forces = (nearly) the minimum-norm member of the non-unique optimal set.
     // (both kept in LDS, not in registers: whatever lives across the fp64 sweep is spilled)
     if (tid == 0) {
-      s.alpha_target = (TV)(cfg.alpha > 0.0 ? cfg.alpha : ((cfg.flags & MPCQP_FLAG_POLISH) ? cfg.alpha_floor : 0.0));
-      s.alpha = ((cfg.flags & MPCQP_FLAG_POLISH) && cfg.alpha < ALPHA_EASY) ? (TV)ALPHA_EASY : (TV)cfg.alpha;
+      s.alpha_target = (TV)cfg.alpha_target;   // (both decided on the host: a double constant compared here lives in a hoisted, spilled register pair)
+      s.alpha = (TV)cfg.alpha_start;
     }
     if (w_setup<TV, TIO, N>(s, cfg, tabs, in, b, tid, first_qp)) {   // non-finite input -> zero outputs, status -1
       for (int i = tid; i < n; i += NT) ug[b * n + i] = (TIO)0;
