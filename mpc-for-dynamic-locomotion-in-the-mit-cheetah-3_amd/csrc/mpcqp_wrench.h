@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void w_admm_sys(const SmemW<TV, N>& s, const DevCfg& 
   if constexpr (sizeof(TM) == 4) sigma = ufloat(sigma);   // (a converted configuration constant is hoisted out of the QP loop: keep it scalar)
   const TM r = (TM)rho, m = (TM)s.mu, a2 = (TM)((TV)2 * s.alpha);
   Ls.dinv[0] = Ls.dinv[1] = stance ? (TM)1 / (a2 + sigma + (TM)2 * r) : (TM)0;
-  Ls.dinv[2] = stance ? (TM)1 / (a2 + sigma + r * ((TM)1 + (TM)4 * m * m)) : (TM)0;
+  Ls.dinv[2] = stance ? (TM)1 / (a2 + sigma + r * fma((TM)4 * m, m, (TM)1)) : (TM)0;   // (an fma: the 1 is an inline operand, not half of a hoisted register pair)
 }
 
 // One ADMM block from the state in s.ua / s.za / s.ya with penalty s.rho.  `adapt`: run the single early rho check (round 0
@@ -1766,7 +1766,7 @@ mpcqp_wrench_solve(const DevCfg* __restrict__ cfgp, const WrTabs tabs, const Fas
       if (tid == 0) {
         statusg[b] = MPCQP_STATUS_NONFINITE;
         itersg[b] = 0;
-        if (resg) { resg[2 * b] = 0.f; resg[2 * b + 1] = 0.f; }
+        if (resg) { const float z = opaque_zero<float>(); resg[2 * b] = z; resg[2 * b + 1] = z; }
       }
       if (!ob.list || !ob.head) break;
       continue;
