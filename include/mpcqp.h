@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define MPCQP_VERSION 0x00010200 /* 1.2.0: round-1 kernels retired (two engines: wrench-space, stage-wise); 1.1.0: horizons up to 64, tuning fields */
+#define MPCQP_VERSION 0x00010300 /* 1.3.0: MpcQpConfig grew by accel / accel_restart (Anderson-accelerated ADMM blocks); 1.2.0: round-1 kernels retired
+                                      (two engines: wrench-space, stage-wise); 1.1.0: horizons up to 64, tuning fields */
 
 /* return codes */
 #define MPCQP_OK 0

@@ -22,7 +22,7 @@ def test_product_library_exports_all_symbols():
     lib = mpcqp.product_library()            # fails loudly if the HIP library has not been built
     for sym in _declared_symbols():
         assert hasattr(lib.lib, sym), sym
-    assert lib.version() == 0x00010200
+    assert lib.version() == 0x00010300
 
 
 def test_oracle_exports_same_symbols(oracle_lib):
